@@ -1,0 +1,87 @@
+"""
+ctypes loader for oracle/libhea_oracle.so (the C restatement, OpenMP over the batch).
+TEST INFRASTRUCTURE ONLY -- see oracle/hea_oracle.c.  Same call shape as the numpy oracle.
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, 'libhea_oracle.so')
+    src = os.path.join(_HERE, 'hea_oracle.c')
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-s', '-C', _HERE, 'libhea_oracle.so'])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, 'libhea_oracle.so')
+        if not os.path.exists(so):
+            so = build()
+        _LIB = ctypes.CDLL(so)
+        d = ctypes.POINTER(ctypes.c_double)
+        i32 = ctypes.POINTER(ctypes.c_int32)
+        _LIB.qhea_oracle_forward.restype = ctypes.c_int
+        _LIB.qhea_oracle_forward.argtypes = [ctypes.c_int, ctypes.c_int, i32, i32, ctypes.c_int64,
+                                             d, d, ctypes.c_double, ctypes.c_double, d, d, d]
+        _LIB.qhea_oracle_backward.restype = ctypes.c_int
+        _LIB.qhea_oracle_backward.argtypes = [ctypes.c_int, ctypes.c_int, i32, i32, ctypes.c_int64,
+                                              d, d, ctypes.c_double, ctypes.c_double, d, d, d, d, d]
+        _LIB.qhea_oracle_threads.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _cfg(block_configs):
+    enc = np.ascontiguousarray([c[0] for c in block_configs], dtype=np.int32)
+    ld = np.ascontiguousarray([c[1] for c in block_configs], dtype=np.int32)
+    i32 = ctypes.POINTER(ctypes.c_int32)
+    return enc, ld, enc.ctypes.data_as(i32), ld.ctypes.data_as(i32)
+
+
+def threads():
+    return lib().qhea_oracle_threads()
+
+
+def hea_forward(num_qubits, block_configs, x, w, offset=0.0, coeff=1.0, ham_diag=None,
+                return_state=False):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    diag = None if ham_diag is None else np.ascontiguousarray(ham_diag, dtype=np.float64)
+    B = x.shape[0]
+    enc, ld, pe, pl = _cfg(block_configs)
+    out = np.empty(B)
+    st = np.empty((B, 1 << num_qubits, 2)) if return_state else None
+    rc = lib().qhea_oracle_forward(num_qubits, len(block_configs), pe, pl, B, _p(x), _p(w),
+                                   float(offset), float(coeff), _p(diag), _p(out), _p(st))
+    if rc:
+        raise ValueError(f"qhea_oracle_forward failed ({rc})")
+    return (out, st) if return_state else out
+
+
+def hea_backward(num_qubits, block_configs, x, w, g, offset=0.0, coeff=1.0, ham_diag=None):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    g = np.ascontiguousarray(g, dtype=np.float64).reshape(-1)
+    diag = None if ham_diag is None else np.ascontiguousarray(ham_diag, dtype=np.float64)
+    B = x.shape[0]
+    enc, ld, pe, pl = _cfg(block_configs)
+    out = np.empty(B)
+    gx = np.zeros_like(x)
+    gw = np.zeros_like(w)
+    rc = lib().qhea_oracle_backward(num_qubits, len(block_configs), pe, pl, B, _p(x), _p(w),
+                                    float(offset), float(coeff), _p(diag), _p(g),
+                                    _p(out), _p(gx), _p(gw))
+    if rc:
+        raise ValueError(f"qhea_oracle_backward failed ({rc})")
+    return out, gx, gw

@@ -1,0 +1,212 @@
+"""
+Checkpoint / weight-format interop.
+
+* ``read_mindspore_ckpt``: dependency-free reader for MindSpore ``.ckpt`` files
+  (protobuf ``Checkpoint{repeated Value value=1}``, ``Value{string tag=1;
+  TensorProto tensor=2}``, ``TensorProto{repeated int64 dims=1; string
+  tensor_type=2; bytes tensor_content=3}``).  Nothing in the file is executed.
+* ``ms_to_pt_state``: MindSpore key names -> QuanONetPT / HEAQNNPT state_dict keys
+  with the ``(P,) -> (blk,3,n)`` reshape.  Mapping follows the reference's
+  ``utils/weight_transfer.py:37-98`` (trunk sub-layers first in the flat vector).
+* ``parse_experiment_dir``: hyper-parameters from the experiment directory name,
+  same grammar as the reference's ``infer.py:37-86`` / ``utils/logger.py:55-118``.
+"""
+import os
+import re
+import numpy as np
+
+_DTYPES = {
+    'Float32': np.dtype('<f4'), 'Float64': np.dtype('<f8'), 'Float16': np.dtype('<f2'),
+    'Int32': np.dtype('<i4'), 'Int64': np.dtype('<i8'),
+}
+
+
+def _varint(buf, pos):
+    val = 0
+    shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        val |= (b & 0x7F) << shift
+        if not (b & 0x80):
+            return val, pos
+        shift += 7
+
+
+def _fields(buf):
+    """Yield (field_number, wire_type, value) over one protobuf message."""
+    pos = 0
+    end = len(buf)
+    while pos < end:
+        key, pos = _varint(buf, pos)
+        fno, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _varint(buf, pos)
+        elif wt == 2:
+            ln, pos = _varint(buf, pos)
+            v = buf[pos:pos + ln]
+            pos += ln
+        elif wt == 1:
+            v = buf[pos:pos + 8]
+            pos += 8
+        elif wt == 5:
+            v = buf[pos:pos + 4]
+            pos += 4
+        else:
+            raise ValueError(f"unsupported protobuf wire type {wt}")
+        yield fno, wt, v
+
+
+def read_mindspore_ckpt(path):
+    """Return {tag: ndarray} for every tensor in a MindSpore .ckpt file."""
+    with open(path, 'rb') as f:
+        buf = f.read()
+    out = {}
+    for fno, wt, val in _fields(buf):
+        if fno != 1 or wt != 2:
+            continue
+        tag = None
+        tensor = None
+        for f2, w2, v2 in _fields(val):
+            if f2 == 1 and w2 == 2:
+                tag = bytes(v2).decode('utf-8')
+            elif f2 == 2 and w2 == 2:
+                tensor = v2
+        if tag is None or tensor is None:
+            continue
+        dims = []
+        ttype = 'Float32'
+        content = b''
+        for f3, w3, v3 in _fields(tensor):
+            if f3 == 1:
+                if w3 == 0:
+                    dims.append(v3)
+                else:                      # packed repeated int64
+                    p = 0
+                    while p < len(v3):
+                        d, p = _varint(v3, p)
+                        dims.append(d)
+            elif f3 == 2:
+                ttype = bytes(v3).decode('utf-8')
+            elif f3 == 3:
+                content = bytes(v3)
+        if ttype not in _DTYPES:
+            raise ValueError(f"{path}: tensor '{tag}' has unsupported type {ttype}")
+        arr = np.frombuffer(content, dtype=_DTYPES[ttype]).copy()
+        shape = [d for d in dims if d > 0]
+        if shape and int(np.prod(shape)) == arr.size:
+            arr = arr.reshape(shape)
+        out[tag] = arr
+    return out
+
+
+def load_weight_file(path):
+    """Load .ckpt (MindSpore protobuf) / .npz / .pt into {name: ndarray}."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == '.ckpt':
+        return read_mindspore_ckpt(path)
+    if ext == '.npz':
+        d = np.load(path, allow_pickle=False)
+        return {k: d[k] for k in d.files}
+    if ext in ('.pt', '.pth'):
+        import torch
+        sd = torch.load(path, map_location='cpu', weights_only=True)
+        return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+    raise ValueError(f"unknown checkpoint extension: {path}")
+
+
+_MS_QUANONET = {
+    'bias': 'bias',
+    'branch_LinearLayer.Net2.weights': 'branch_freq.weights',
+    'branch_LinearLayer.Net2.bias': 'branch_freq.bias',
+    'trunk_LinearLayer.Net2.weights': 'trunk_freq.weights',
+    'trunk_LinearLayer.Net2.bias': 'trunk_freq.bias',
+}
+_MS_HEAQNN = {
+    'LinearLayer.Net2.weights': 'freq.weights',
+    'LinearLayer.Net2.bias': 'freq.bias',
+}
+
+
+def is_mindspore_state(state):
+    return 'QuanONet.weight' in state or 'HEAQNN.weight' in state
+
+
+def ms_to_pt_state(state, num_qubits, net_size, model_type='QuanONet', dtype=np.float64):
+    """
+    MindSpore-named arrays -> PT-named arrays (utils/weight_transfer.py:46-98).
+    Frequency-layer keys are mapped when present (trainable-frequency checkpoints).
+    """
+    n = int(num_qubits)
+    out = {}
+    if model_type == 'QuanONet':
+        bd, bl, td, tl = net_size
+        blk = bd * bl + td * tl
+        raw = np.asarray(state['QuanONet.weight'], dtype=dtype).reshape(-1)
+        names = _MS_QUANONET
+    elif model_type == 'HEAQNN':
+        blk = net_size[0] * net_size[1]
+        raw = np.asarray(state['HEAQNN.weight'], dtype=dtype).reshape(-1)
+        names = _MS_HEAQNN
+    else:
+        raise ValueError(f"unsupported model_type {model_type}")
+    if raw.size != blk * 3 * n:
+        raise ValueError(f"circuit weight has {raw.size} elements but expected {blk * 3 * n} "
+                         f"({blk}x3x{n}); check net_size and num_qubits")
+    out['quantum_layer.ansatz_weights'] = raw.reshape(blk, 3, n)
+    for ms_key, pt_key in names.items():
+        if ms_key in state:
+            v = np.asarray(state[ms_key], dtype=dtype)
+            out[pt_key] = v.reshape(1) if pt_key == 'bias' else v.reshape(-1)
+    return out
+
+
+def pt_to_ms_state(state, model_type='QuanONet'):
+    """Inverse of ms_to_pt_state (flat circuit vector, MindSpore key names)."""
+    inv = {v: k for k, v in (_MS_QUANONET if model_type == 'QuanONet' else _MS_HEAQNN).items()}
+    out = {}
+    for k, v in state.items():
+        v = np.asarray(v)
+        if k == 'quantum_layer.ansatz_weights':
+            out[f'{model_type}.weight'] = v.reshape(-1)
+        elif k in inv:
+            out[inv[k]] = v.reshape(()) if k == 'bias' else v
+    return out
+
+
+_NET_RE = re.compile(r'Net(\d+)-(\d+)-(\d+)-(\d+)')
+_NET2_RE = re.compile(r'Net(\d+)-(\d+)(?:[^-\d]|$)')
+_Q_RE = re.compile(r'_Q(\d+)')
+_S_RE = re.compile(r'_S([\d.]+?)(?:_|$)')
+_TF_RE = re.compile(r'_(TF|FF|NTF)(?:_|$)')
+_MODEL_RE = re.compile(r'_(QuanONet|HEAQNN)_')
+
+
+def parse_experiment_dir(path):
+    """Hyper-parameters encoded in an experiment directory name (infer.py:60-86)."""
+    name = path
+    if os.path.splitext(path)[1]:
+        name = os.path.basename(os.path.dirname(os.path.abspath(path)))
+    else:
+        name = os.path.basename(os.path.normpath(path))
+    cfg = {}
+    m = _MODEL_RE.search(name)
+    if m:
+        cfg['model_type'] = m.group(1)
+    m = _NET_RE.search(name)
+    if m:
+        cfg['net_size'] = [int(m.group(i)) for i in range(1, 5)]
+    else:
+        m = _NET2_RE.search(name)
+        if m:
+            cfg['net_size'] = [int(m.group(1)), int(m.group(2))]
+    m = _Q_RE.search(name)
+    if m:
+        cfg['num_qubits'] = int(m.group(1))
+    m = _S_RE.search(name)
+    if m:
+        cfg['scale_coeff'] = float(m.group(1))
+    m = _TF_RE.search(name)
+    if m:
+        cfg['if_trainable_freq'] = (m.group(1) == 'TF')
+    return cfg

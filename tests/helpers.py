@@ -1,0 +1,57 @@
+"""Shared helpers for the parity tests (test infrastructure; may import oracle/)."""
+import json
+import os
+import numpy as np
+
+from oracle import hea_oracle as O
+from quanonet_amd.checkpoint import ms_to_pt_state
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_pt_params(fname, n, net_size):
+    d = np.load(os.path.join(GOLDEN, fname), allow_pickle=False)
+    return ms_to_pt_state({k: d[k] for k in d.files}, n, net_size)
+
+
+def known_answers():
+    with open(os.path.join(GOLDEN, 'known_answers.json')) as f:
+        return json.load(f)
+
+
+def notebook_inputs(npts, u0_fn):
+    """visualization.ipynb cell 7: float32 grids, meshgrid 'xy', branch tiled."""
+    x0 = np.linspace(0, 1, 100).astype(np.float32)
+    x = np.linspace(0, 1, npts).astype(np.float32)
+    X, YT = np.meshgrid(x, x)
+    trunk = np.hstack((X.flatten()[:, None], YT.flatten()[:, None])).astype(np.float32)
+    branch = np.tile(u0_fn(x0), (trunk.shape[0], 1)).astype(np.float32)
+    return branch, trunk
+
+
+U0 = {'sin2pi': lambda x: np.sin(2 * np.pi * x), 'sin4pi': lambda x: np.sin(4 * np.pi * x)}
+PDE_CASES = [('K3', 'advection', 'sin2pi', 100), ('K4', 'advection', 'sin4pi', 100),
+             ('K5', 'rdiffusion', 'sin2pi', 100), ('K6', 'rdiffusion', 'sin4pi', 100),
+             ('K7', 'darcy', 'sin2pi', 25), ('K8', 'darcy', 'sin4pi', 25)]
+
+
+def encode_quanonet(params, branch, trunk):
+    """x[B,E] = cat(trunk_enc, branch_enc) in fp64 (models_pt.py:161-164)."""
+    t = O.tiled_elementwise(trunk, params['trunk_freq.weights'], params['trunk_freq.bias'])
+    b = O.tiled_elementwise(branch, params['branch_freq.weights'], params['branch_freq.bias'])
+    return np.concatenate([t, b], axis=1)
+
+
+def fmt1e(v):
+    return f'{v:.1e}'
+
+
+def golden_vectors():
+    V = np.load(os.path.join(GOLDEN, 'hea_vectors.npz'), allow_pickle=False)
+    names = sorted({k.split('.')[0] for k in V.files})
+    out = {}
+    for nm in names:
+        out[nm] = dict(n=int(V[nm + '.n']), cfgs=[tuple(int(v) for v in r) for r in V[nm + '.cfgs']],
+                       x=V[nm + '.x'], w=V[nm + '.w'], g=V[nm + '.g'], out=V[nm + '.out'],
+                       grad_x=V[nm + '.grad_x'], grad_w=V[nm + '.grad_w'])
+    return out

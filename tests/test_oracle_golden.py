@@ -1,0 +1,147 @@
+"""
+Pins the CPU oracle (numpy + C restatements) against the reference's known answers
+ and against mathematics (parameter-shift identity).
+CPU only.
+"""
+import numpy as np
+import pytest
+
+from oracle import hea_oracle as O
+from oracle import c_oracle as C
+from tests import helpers as H
+
+
+def test_k1_k2_antiderivative_analytic():
+    # ibm_inference.py:176-187: branch on 10 sensors, trunk linspace(0,1,100)
+    p = H.load_pt_params('antideriv_q2.npz', 2, (5, 1, 5, 1))
+    trunk = np.linspace(0, 1, 100)[:, None]
+    ka = H.known_answers()
+    for key, bv, truth in [('K1', np.cos(np.pi * np.linspace(0, 1, 10)), np.sin(np.pi * trunk[:, 0]) / np.pi),
+                           ('K2', np.linspace(0, 1, 10), 0.5 * trunk[:, 0] ** 2)]:
+        out = O.quanonet_forward(p, np.tile(bv, (100, 1)), trunk, 2, (5, 1, 5, 1))
+        rel = np.linalg.norm(out - truth) / np.linalg.norm(truth)
+        assert rel < ka[key]['rel_l2_max']
+        assert abs(rel - ka[key]['survey_rel_l2']) < 2e-3       # the survey's scratch restatement value
+
+
+@pytest.mark.parametrize('key,op,tag,npts', H.PDE_CASES)
+def test_k3_k8_notebook_figures(key, op, tag, npts):
+    # visualization.ipynb cell 7: MSE/MAE printed with 2 significant digits in the figure titles
+    ka = H.known_answers()[key]
+    p = H.load_pt_params(f'{op}_q5.npz', 5, (40, 2, 20, 2))
+    branch, trunk = H.notebook_inputs(npts, H.U0[tag])
+    x = H.encode_quanonet(p, branch, trunk)
+    off, co = O.ham_params(5, -5.0, 5.0)
+    cfgs = O.block_configs_quanonet(5, (40, 2, 20, 2))
+    out = C.hea_forward(5, cfgs, x, p['quantum_layer.ansatz_weights'], off, co) + p['bias'][0]
+    truth = np.load(H.GOLDEN + '/pde_truths.npz')[f'{op}_{tag}']
+    diff = truth - out.reshape(npts, npts)
+    assert H.fmt1e(np.mean(diff ** 2)) == ka['mse']
+    assert H.fmt1e(np.mean(np.abs(diff))) == ka['mae']
+
+
+def test_flipped_cnot_is_detected():
+    # sanity of the pin itself: reversing the entangler direction destroys K1 (survey: 633 %)
+    p = H.load_pt_params('antideriv_q2.npz', 2, (5, 1, 5, 1))
+    trunk = np.linspace(0, 1, 100)[:, None]
+    bv = np.cos(np.pi * np.linspace(0, 1, 10))
+    truth = np.sin(np.pi * trunk[:, 0]) / np.pi
+    orig = O._cnot
+    try:
+        O._cnot = lambda psi, n, c, t: orig(psi, n, t, c)
+        out = O.quanonet_forward(p, np.tile(bv, (100, 1)), trunk, 2, (5, 1, 5, 1))
+    finally:
+        O._cnot = orig
+    assert np.linalg.norm(out - truth) / np.linalg.norm(truth) > 1.0
+
+
+def test_numpy_and_c_oracles_agree_on_golden_vectors():
+    for nm, v in H.golden_vectors().items():
+        off, co = O.ham_params(v['n'])
+        out, gx, gw = C.hea_backward(v['n'], v['cfgs'], v['x'], v['w'], v['g'], off, co)
+        np.testing.assert_allclose(out, v['out'], rtol=0, atol=1e-12, err_msg=nm)
+        np.testing.assert_allclose(gx, v['grad_x'], rtol=0, atol=1e-12, err_msg=nm)
+        np.testing.assert_allclose(gw, v['grad_w'], rtol=0, atol=1e-12, err_msg=nm)
+        f = C.hea_forward(v['n'], v['cfgs'], v['x'], v['w'], off, co)
+        np.testing.assert_allclose(f, v['out'], rtol=0, atol=1e-12, err_msg=nm)
+
+
+def test_numpy_oracle_regression_small():
+    v = H.golden_vectors()['q3_small']
+    off, co = O.ham_params(3)
+    out, gx, gw = O.hea_backward(3, v['cfgs'], v['x'], v['w'], v['g'], off, co)
+    np.testing.assert_allclose(out, v['out'], atol=1e-13)
+    np.testing.assert_allclose(gx, v['grad_x'], atol=1e-13)
+    np.testing.assert_allclose(gw, v['grad_w'], atol=1e-13)
+
+
+@pytest.mark.parametrize('n,cfgs', [(2, [(2, 1), (2, 2)]), (3, [(3, 2), (3, 1)]), (5, [(5, 2)] * 3)])
+def test_adjoint_matches_parameter_shift(n, cfgs):
+    rng = np.random.default_rng(n)
+    E, blk = O.circuit_sizes(n, cfgs)
+    B = 4
+    x = rng.uniform(-np.pi, np.pi, (B, E))
+    w = rng.uniform(-np.pi, np.pi, (blk, 3, n))
+    g = rng.normal(size=B)
+    off, co = O.ham_params(n, -3.0, 7.0)
+    out, gx, gw = C.hea_backward(n, cfgs, x, w, g, off, co)
+    for idx in [(0, 0, 0), (blk - 1, 2, n - 1), (blk // 2, 1, n // 2)]:
+        ps = O.param_shift_grad_w(n, cfgs, x, w, g, off, co, idx)
+        assert abs(ps - gw[idx]) < 1e-10
+    for col in [0, E - 1, E // 2]:
+        ps = O.param_shift_grad_x(n, cfgs, x, w, g, off, co, col)
+        np.testing.assert_allclose(gx[:, col], ps, atol=1e-10)
+
+
+def test_state_norm_and_output_range():
+    n, cfgs = 4, [(4, 2)] * 3
+    rng = np.random.default_rng(0)
+    E, blk = O.circuit_sizes(n, cfgs)
+    x = rng.uniform(-4, 4, (8, E))
+    w = rng.uniform(-4, 4, (blk, 3, n))
+    out, st = C.hea_forward(n, cfgs, x, w, *O.ham_params(n, -5, 5), return_state=True)
+    np.testing.assert_allclose((st ** 2).sum(axis=(1, 2)), 1.0, atol=1e-12)
+    assert np.all(out >= -5 - 1e-12) and np.all(out <= 5 + 1e-12)
+
+
+def test_ham_diag_readout_little_endian():
+    # parity unpinned in the reference; we fix bit i of k = wire i and check
+    # that the simple Hamiltonian is the special case diag[k] = off + co*(n - 2 popcount k)
+    n, cfgs = 3, [(3, 1), (3, 1)]
+    rng = np.random.default_rng(5)
+    E, blk = O.circuit_sizes(n, cfgs)
+    x = rng.uniform(-3, 3, (5, E))
+    w = rng.uniform(-3, 3, (blk, 3, n))
+    off, co = O.ham_params(n, -5, 5)
+    d = O.ham_diagonal(n, off, co)
+    a = C.hea_forward(n, cfgs, x, w, off, co)
+    b = C.hea_forward(n, cfgs, x, w, 0.0, 0.0, ham_diag=d)
+    np.testing.assert_allclose(a, b, atol=1e-13)
+    d2 = rng.normal(size=8)
+    np.testing.assert_allclose(C.hea_forward(n, cfgs, x, w, 0, 0, ham_diag=d2),
+                               O.hea_forward(n, cfgs, x, w, 0, 0, ham_diag=d2), atol=1e-13)
+
+
+def test_quanonet_loss_grads_finite_difference():
+    n, ns = 2, (2, 1, 2, 1)
+    rng = np.random.default_rng(3)
+    p = {
+        'trunk_freq.weights': rng.normal(size=4), 'trunk_freq.bias': rng.normal(size=4),
+        'branch_freq.weights': rng.normal(size=4), 'branch_freq.bias': rng.normal(size=4),
+        'quantum_layer.ansatz_weights': rng.uniform(-3, 3, (4, 3, 2)), 'bias': np.array([0.3]),
+    }
+    br = rng.normal(size=(6, 3))
+    tr = rng.uniform(size=(6, 1))
+    y = rng.normal(size=6)
+    loss, grads, _ = O.quanonet_loss_and_grads(p, br, tr, y, n, ns)
+    eps = 1e-6
+    for key in p:
+        flat = p[key].reshape(-1)
+        i = flat.size // 2
+        old = flat[i]
+        flat[i] = old + eps
+        lp = O.quanonet_loss_and_grads(p, br, tr, y, n, ns)[0]
+        flat[i] = old - eps
+        lm = O.quanonet_loss_and_grads(p, br, tr, y, n, ns)[0]
+        flat[i] = old
+        assert abs((lp - lm) / (2 * eps) - grads[key].reshape(-1)[i]) < 1e-7, key
