@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the MI355X-native QuanONet training path.
+
+Workload (BASELINE.json configs[1]): Advection-shaped QuanONet, Q=5, Net40-2-20-2, b_in=100, t_in=2,
+batch 1024 PER GPU (weak scaling), fp64, synthetic data.  One "step" is one
+full training step of the hot path: frequency layers -> HIP circuit forward -> MSE -> in-kernel adjoint
+backward -> (RCCL all-reduce of the flat gradient when N>1) -> Adam.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run,
+one rank per GPU.  Rank 0 prints ONE JSON line.  `value` = train samples/s over all ranks; the same line
+also carries forward-only circuit-evals/s, the roofline object of the dominant kernel and the CPU baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_QUBITS, NET, B_IN, T_IN, BATCH = 5, (40, 2, 20, 2), 100, 2, 1024
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def circuit_counts(n, net):
+    bd, bl, td, tl = net
+    E = (bd + td) * n
+    blk = bd * bl + td * tl
+    R = E + 3 * n * blk                 # rotation gates
+    G = R + n * blk                     # + CNOTs
+    S = 16 * (1 << n)                   # bytes of one fp64 complex state
+    return dict(E=E, blk=blk, R=R, G=G, S=S,
+                bytes_fwd=2 * S * G + S,                 # gate-streaming model, BASELINE.md section 2
+                bytes_bwd=S * (4 * G + 2 * R),           # reverse sweep on psi and lambda + <lam|.|psi> passes
+                bytes_train=S * (6 * G + 2 * R) + S)
+
+
+def synth(rank, n_samples):
+    rng = np.random.default_rng(1000 + rank)
+    branch = rng.normal(size=(n_samples, B_IN))
+    trunk = rng.uniform(size=(n_samples, T_IN))
+    y = rng.normal(scale=0.5, size=(n_samples, 1))
+    return branch, trunk, y
+
+
+def cpu_baseline(seconds_target=12.0):
+    """Oracle (C + OpenMP over the batch) timed on this host: training = forward + adjoint backward."""
+    from oracle import c_oracle as C, hea_oracle as O
+    cfgs = O.block_configs_quanonet(N_QUBITS, NET)
+    E, blk = O.circuit_sizes(N_QUBITS, cfgs)
+    rng = np.random.default_rng(0)
+    w = rng.uniform(-np.pi, np.pi, (blk, 3, N_QUBITS))
+    off, co = O.ham_params(N_QUBITS)
+    cores = C.threads()
+    nb = 256 * max(1, cores // 4)
+    x = rng.uniform(-np.pi, np.pi, (nb, E))
+    g = rng.normal(size=nb)
+    C.hea_backward(N_QUBITS, cfgs, x[:64], w, g[:64], off, co)            # warm
+    t0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t0 < seconds_target:
+        C.hea_backward(N_QUBITS, cfgs, x, w, g, off, co)
+        done += nb
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    C.hea_forward(N_QUBITS, cfgs, x, w, off, co)
+    dtf = time.perf_counter() - t1
+    return {"value": done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{done} train samples (forward + adjoint backward of the Q5 Net40-2-20-2 circuit, "
+                      f"oracle/hea_oracle.c, OpenMP over the batch), {dt:.1f} s",
+            "forward_evals_per_s": nb / dtf}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from quanonet_amd.models import QuanONetPT
+    from quanonet_amd import _lib
+    from quanonet_amd.solver import DataParallelTrainer
+
+    torch.manual_seed(0)
+    model = QuanONetPT(N_QUBITS, B_IN, T_IN, NET, scale_coeff=0.1, if_trainable_freq=True).to(dev)
+    trainer = DataParallelTrainer(model, lr=1e-4, world_size=world, dist=dist)
+
+    n_batches = 8                                             # device-resident synthetic set, cycled
+    branch, trunk, y = synth(rank, n_batches * BATCH)
+    branch = torch.tensor(branch, device=dev); trunk = torch.tensor(trunk, device=dev); y = torch.tensor(y, device=dev)
+
+    def step(i):
+        s = (i % n_batches) * BATCH
+        return trainer.train_step(branch[s:s + BATCH], trunk[s:s + BATCH], y[s:s + BATCH],
+                                  global_batch=BATCH * world)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    samples_per_s = BATCH * world * args.steps / elapsed
+
+    # forward-only circuit evaluations/s (evaluation path), same batch
+    with torch.no_grad():
+        for i in range(5):
+            model(branch[:BATCH], trunk[:BATCH])
+        fence()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            model(branch[:BATCH], trunk[:BATCH])
+        fence()
+        fwd_elapsed = time.perf_counter() - t1
+    evals_per_s = BATCH * world * args.steps / fwd_elapsed
+
+    # dominant kernel (adjoint backward launch sequence), HIP events on the launch stream
+    cc = circuit_counts(N_QUBITS, NET)
+    roof = None
+    if rank == 0:
+        sh = model.quantum_layer._shape
+        x = torch.rand(BATCH, sh.E, device=dev, dtype=torch.float64) * 6 - 3
+        w = model.quantum_layer.ansatz_weights.detach()
+        g = torch.randn(BATCH, device=dev, dtype=torch.float64)
+        off, co = model.quantum_layer.ham_offset, model.quantum_layer.ham_coeff
+        _, st = _lib.hea_forward(sh, x, w, off, co, return_state=True)
+        reps = max(20, min(args.steps, 200))
+        for _ in range(5):
+            _lib.hea_backward(sh, x, w, g, off, co, state=st)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record(); _lib.hea_backward(sh, x, w, g, off, co, state=st); b.record()
+        torch.cuda.synchronize()
+        bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        evf = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evf:
+            a.record(); _lib.hea_forward(sh, x, w, off, co); b.record()
+        torch.cuda.synchronize()
+        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in evf]))
+        achieved = cc['bytes_bwd'] * BATCH / (bwd_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "qhea::bwd_kernel<5> (+prep, reduce)", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "launch_ms": bwd_ms, "algorithmic_bytes_per_launch": cc['bytes_bwd'] * BATCH,
+                "fwd_launch_ms": fwd_ms,
+                "fwd_achieved": cc['bytes_fwd'] * BATCH / (fwd_ms * 1e-3) / 1e9,
+                "note": "gate-streaming algorithmic bytes; the state is wave-resident so real HBM traffic is "
+                        "inputs+outputs only and frac may exceed 1 (see DESIGN.md)"}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        line = {
+            "metric": "train samples/sec (circuit-evals/sec alongside), QuanONet Q=5 Net40-2-20-2 Advection",
+            "value": samples_per_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Advection QuanONet Q=5 Net40-2-20-2 b_in=100 t_in=2, batch 1024 per GPU, "
+                                   "fp64, Adam lr=1e-4, trainable frequency",
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}"},
+            "circuit_evals_per_s": evals_per_s,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,148 @@
+"""
+ctypes binding of the C ABI in include/quanonet_hea.h (libquanonet_hea.so, built in-tree by
+``__graft_entry__.build()`` / ``quanonet_amd/csrc/Makefile``).
+
+There is deliberately NO CPU fallback: if the shared library is missing, or a tensor is not on
+a HIP device, the calls raise.  torch is used only for device memory and streams.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libquanonet_hea.so')
+
+EXPORTS = ['qhea_version', 'qhea_strerror', 'qhea_device_count', 'qhea_workspace_bytes',
+           'qhea_forward', 'qhea_backward']
+
+_lib = None
+
+
+class QheaError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libquanonet_hea.so (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QheaError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                        f"g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, dp = ctypes.c_void_p, ctypes.c_void_p
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    lib.qhea_version.restype = ctypes.c_int
+    lib.qhea_strerror.restype = ctypes.c_char_p
+    lib.qhea_strerror.argtypes = [ctypes.c_int]
+    lib.qhea_device_count.restype = ctypes.c_int
+    lib.qhea_workspace_bytes.restype = ctypes.c_size_t
+    lib.qhea_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, i32p, i32p, ctypes.c_int64]
+    lib.qhea_forward.restype = ctypes.c_int
+    lib.qhea_forward.argtypes = [ctypes.c_int, ctypes.c_int, i32p, i32p, ctypes.c_int64, dp, dp,
+                                 ctypes.c_double, ctypes.c_double, dp, dp, dp, vp, ctypes.c_size_t, vp]
+    lib.qhea_backward.restype = ctypes.c_int
+    lib.qhea_backward.argtypes = [ctypes.c_int, ctypes.c_int, i32p, i32p, ctypes.c_int64, dp, dp,
+                                  ctypes.c_double, ctypes.c_double, dp, dp, dp, dp, dp, dp,
+                                  vp, ctypes.c_size_t, vp]
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise QheaError(f"{what} failed: {load().qhea_strerror(rc).decode()} ({rc})")
+
+
+class CircuitShape:
+    """Host-side description of the block list; owns the int32 arrays handed to the C ABI."""
+
+    def __init__(self, num_qubits, block_configs):
+        self.n = int(num_qubits)
+        self.block_configs = [(int(a), int(b)) for a, b in block_configs]
+        nb = len(self.block_configs)
+        self._enc = (ctypes.c_int32 * max(nb, 1))(*[c[0] for c in self.block_configs])
+        self._ld = (ctypes.c_int32 * max(nb, 1))(*[c[1] for c in self.block_configs])
+        self.nb = nb
+        self.E = sum(c[0] for c in self.block_configs)
+        self.blk = sum(c[1] for c in self.block_configs)
+
+    def workspace_bytes(self, batch):
+        return int(load().qhea_workspace_bytes(self.n, self.nb, self._enc, self._ld, int(batch)))
+
+
+def _dev_f64(t, name, shape=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise QheaError(f"{name} must live on a HIP device (got {t.device}); there is no CPU path")
+    if t.dtype != torch.float64 or not t.is_contiguous():
+        raise QheaError(f"{name} must be a contiguous float64 tensor")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise QheaError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    """Grow-only per-device scratch tensor (caller-owned from the C ABI's point of view)."""
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def hea_forward(shape, x, w, ham_offset, ham_coeff, ham_diag=None, return_state=False):
+    """out[B] (and optionally the final state [B,2^n,2]) on x.device.  No bias."""
+    lib = load()
+    B = x.shape[0]
+    _dev_f64(x, 'x', (B, shape.E))
+    _dev_f64(w, 'w', (shape.blk, 3, shape.n))
+    _dev_f64(ham_diag, 'ham_diag', (1 << shape.n,))
+    out = torch.empty(B, dtype=torch.float64, device=x.device)
+    state = torch.empty((B, 1 << shape.n, 2), dtype=torch.float64, device=x.device) if return_state else None
+    nbytes = shape.workspace_bytes(B)
+    ws = _workspace(x.device, nbytes)
+    with torch.cuda.device(x.device):
+        rc = lib.qhea_forward(shape.n, shape.nb, shape._enc, shape._ld, B, _ptr(x), _ptr(w),
+                              float(ham_offset), float(ham_coeff), _ptr(ham_diag), _ptr(out), _ptr(state),
+                              _ptr(ws), ws.numel(), _stream(x.device))
+    _check(rc, 'qhea_forward')
+    return (out, state) if return_state else out
+
+
+def hea_backward(shape, x, w, g, ham_offset, ham_coeff, ham_diag=None, state=None, want_out=False):
+    """(grad_x[B,E], grad_w[blk,3,n][, out[B]]) for upstream g[B]."""
+    lib = load()
+    B = x.shape[0]
+    _dev_f64(x, 'x', (B, shape.E))
+    _dev_f64(w, 'w', (shape.blk, 3, shape.n))
+    _dev_f64(g, 'g', (B,))
+    _dev_f64(ham_diag, 'ham_diag', (1 << shape.n,))
+    _dev_f64(state, 'state', (B, 1 << shape.n, 2))
+    grad_x = torch.empty_like(x)
+    grad_w = torch.empty_like(w)
+    out = torch.empty(B, dtype=torch.float64, device=x.device) if want_out else None
+    nbytes = shape.workspace_bytes(B)
+    ws = _workspace(x.device, nbytes)
+    with torch.cuda.device(x.device):
+        rc = lib.qhea_backward(shape.n, shape.nb, shape._enc, shape._ld, B, _ptr(x), _ptr(w),
+                               float(ham_offset), float(ham_coeff), _ptr(ham_diag), _ptr(g), _ptr(state),
+                               _ptr(out), _ptr(grad_x), _ptr(grad_w), _ptr(ws), ws.numel(),
+                               _stream(x.device))
+    _check(rc, 'qhea_backward')
+    return (grad_x, grad_w, out) if want_out else (grad_x, grad_w)

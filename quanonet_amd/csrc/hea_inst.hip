@@ -1,0 +1,22 @@
+// hea_inst.hip -- instantiates the wave-resident forward/backward kernels for ONE qubit count
+// (compile with -DQHEA_N=<n>; one object per n keeps the build parallel).
+#include "hea_device.hpp"
+
+#ifndef QHEA_N
+#error "compile with -DQHEA_N=<qubits>"
+#endif
+#define QHEA_CAT_(a, b) a##b
+#define QHEA_CAT(a, b) QHEA_CAT_(a, b)
+
+namespace qhea {
+
+void QHEA_CAT(launch_fwd_, QHEA_N)(dim3 grid, hipStream_t st, const FwdArgs& a) {
+    hipLaunchKernelGGL(fwd_kernel<QHEA_N>, grid, dim3(kWaves * 64), 0, st, a.runs, a.B, a.E, a.cs, a.U, a.off,
+                       a.co, a.diag, a.out, a.state_out);
+}
+void QHEA_CAT(launch_bwd_, QHEA_N)(dim3 grid, hipStream_t st, const BwdArgs& a) {
+    hipLaunchKernelGGL(bwd_kernel<QHEA_N>, grid, dim3(kWaves * 64), 0, st, a.runs, a.B, a.E, a.blk, a.cs, a.U,
+                       a.off, a.co, a.diag, a.g, a.state_in, a.out, a.grad_x, a.partial);
+}
+
+}  // namespace qhea

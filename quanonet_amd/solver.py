@@ -1,0 +1,235 @@
+"""
+Training loop for QuanONetPT / HEAQNNPT on the HIP quantum layer: host-side mirror of the
+reference's ``solvers/solver_pt.py`` (PTSolver) plus the data-parallel step the reference lacks.
+
+* ``DataParallelTrainer``: one training step = forward -> MSE -> in-kernel adjoint backward ->
+  ONE all-reduce (SUM) of a flat fp64 buffer [all gradients | sse | sum y^2] -> Adam.
+  Each rank's loss is ``sum((pred-y)^2) / global_batch`` so that a plain SUM reproduces the
+  gradient of ``MSELoss(mean)`` over the global batch (solver_pt.py:232-236), also for uneven
+  shards.  The two logging scalars ride in the same buffer, removing the reference's two
+  ``.item()`` host syncs per batch (solver_pt.py:238-241).
+* ``PTSolver``: config-dict driven epoch/batch loop with the reference's semantics
+  (solver_pt.py:191-329): ``np.random.permutation`` batch order, best-by-train-loss checkpoint
+  as ``.pt`` + ``.npz`` with the reference's state_dict keys, final checkpoint, evaluate() with
+  rel-L2 / MSE / MAE / max-error.  Training data stay resident on the device.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def shard_slice(n_items, rank, world):
+    """Contiguous, near-even shard [lo, hi) of a batch of n_items for `rank` of `world`."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class DataParallelTrainer:
+    def __init__(self, model, lr=1e-4, world_size=1, dist=None, optimizer='adam', optimizer_kwargs=None):
+        self.model = model
+        self.world = int(world_size)
+        self.dist = dist
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        p0 = self.params[0]
+        self.numel = sum(p.numel() for p in self.params)
+        # flat gradient buffer; .grad of every parameter is a view into it (+2 logging scalars)
+        self.flat = torch.zeros(self.numel + 2, dtype=torch.float64, device=p0.device)
+        off = 0
+        for p in self.params:
+            if p.dtype != torch.float64:
+                raise ValueError("DataParallelTrainer expects float64 parameters (fp64 training path)")
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        kw = dict(optimizer_kwargs or {})
+        opt_map = {'adam': torch.optim.Adam, 'adamw': torch.optim.AdamW, 'sgd': torch.optim.SGD,
+                   'rmsprop': torch.optim.RMSprop}
+        cls = opt_map.get(optimizer.lower(), torch.optim.Adam)
+        if cls in (torch.optim.Adam, torch.optim.AdamW) and p0.is_cuda and 'fused' not in kw:
+            kw['fused'] = True
+        self.optimizer = cls(self.params, lr=lr, **kw)
+        if self.world > 1:
+            self.broadcast_parameters()
+
+    def broadcast_parameters(self):
+        for p in self.params:
+            self.dist.broadcast(p.data, src=0)
+
+    def _forward(self, inputs):
+        if isinstance(inputs, (tuple, list)):
+            return self.model(*inputs)
+        return self.model(inputs)
+
+    def train_step(self, *batch, global_batch=None):
+        """batch = (branch, trunk, y) or (x, y): this rank's shard.  Returns the flat buffer (device)."""
+        *inputs, y = batch
+        gb = float(global_batch if global_batch is not None else y.shape[0] * self.world)
+        self.flat.zero_()
+        pred = self._forward(inputs)
+        resid = pred - y.reshape(pred.shape)
+        sse = (resid * resid).sum()
+        (sse / gb).backward()
+        with torch.no_grad():
+            self.flat[self.numel] = sse
+            self.flat[self.numel + 1] = (y * y).sum()
+        if self.world > 1:
+            self.dist.all_reduce(self.flat)            # SUM; one latency-bound message (19 KB at Q5)
+        self.optimizer.step()
+        return self.flat
+
+    def loss_scalars(self):
+        """(sse, sum y^2) of the last global batch -- forces a device sync; call per epoch, not per step."""
+        v = self.flat[self.numel:].tolist()
+        return v[0], v[1]
+
+
+class PTSolver:
+    """
+    Mirror of the reference PTSolver (solvers/solver_pt.py:21-329).  ``config`` uses the reference's
+    keys (model_type, operator, num_qubits, net_size, scale_coeff, if_trainable_freq, ham_bound,
+    ham_diag, learning_rate, batch_size, num_epochs, optimizer, lr_scheduler, if_save, prefix, seed).
+    ``data_dict`` has the DataManager output keys (data_utils/data_manager.py:74-106):
+    train_branch_input/train_trunk_input/train_output/test_* (QuanONet) or train_input/... (HEAQNN).
+    """
+
+    def __init__(self, config, data_dict, device=None, dist=None, rank=0, world_size=1, log=print):
+        self.config = config
+        self.data_dict = data_dict
+        self.model_type = config['model_type']
+        self.dist, self.rank, self.world = dist, rank, world_size
+        self.log = log if rank == 0 else (lambda *a, **k: None)
+        self.device = device if device is not None else torch.device('cuda')
+        if self.device.type != 'cuda':
+            raise RuntimeError("PTSolver runs on a HIP device only (no CPU fallback)")
+        self.out_dir = os.path.join(config.get('prefix') or 'outputs', config.get('operator', 'Op'),
+                                    config.get('run_id', 'run'))
+        self.model = self._create_model().to(self.device)
+        self.trainer = DataParallelTrainer(self.model, lr=config['learning_rate'], world_size=world_size,
+                                           dist=dist, optimizer=config.get('optimizer', 'adam'),
+                                           optimizer_kwargs=config.get('optimizer_kwargs', {}))
+        self.lr_scheduler = self._build_scheduler()
+        self.best_loss = float('inf')
+        self.best_model_path = None
+        self._setup_data()
+
+    # ---- model / data -------------------------------------------------------------------------
+    def _create_model(self):
+        from .models import QuanONetPT, HEAQNNPT
+        c = self.config
+        ham_bound = tuple(c.get('ham_bound', [-5, 5]))
+        net_size = tuple(c.get('net_size', [20, 2, 10, 2]))
+        if_tf = str(c.get('if_trainable_freq', 'true')).lower() == 'true'
+        scale = float(c.get('scale_coeff', 0.01))
+        n = int(c['num_qubits'])
+        if self.model_type == 'QuanONet':
+            return QuanONetPT(n, self.data_dict['train_branch_input'].shape[1],
+                              self.data_dict['train_trunk_input'].shape[1], net_size, scale_coeff=scale,
+                              if_trainable_freq=if_tf, ham_bound=ham_bound, ham_diag=c.get('ham_diag'))
+        if self.model_type == 'HEAQNN':
+            return HEAQNNPT(n, self.data_dict['train_input'].shape[1], net_size, scale_coeff=scale,
+                            if_trainable_freq=if_tf, ham_bound=ham_bound, ham_diag=c.get('ham_diag'))
+        raise ValueError(f"PTSolver does not support model_type='{self.model_type}'")
+
+    def _dev(self, a):
+        return torch.as_tensor(np.asarray(a), dtype=torch.float64).to(self.device)
+
+    def _setup_data(self):
+        d = self.data_dict
+        if self.model_type == 'HEAQNN':
+            self.train_input = (self._dev(d['train_input']),)
+            self.test_input = (self._dev(d['test_input']),)
+        else:
+            self.train_input = (self._dev(d['train_branch_input']), self._dev(d['train_trunk_input']))
+            self.test_input = (self._dev(d['test_branch_input']), self._dev(d['test_trunk_input']))
+        self.train_output = self._dev(d['train_output']).reshape(len(d['train_output']), -1)
+        self.test_output = np.asarray(d['test_output'], dtype=np.float64).reshape(len(d['test_output']), -1)
+
+    def _build_scheduler(self):
+        name = str(self.config.get('lr_scheduler', 'none')).lower()
+        kw = self.config.get('lr_scheduler_kwargs', {})
+        opt = self.trainer.optimizer
+        if name == 'cosine':
+            return torch.optim.lr_scheduler.CosineAnnealingLR(
+                opt, T_max=kw.get('T_max', self.config.get('num_epochs', 1000)), eta_min=kw.get('eta_min', 0.0))
+        if name == 'step':
+            return torch.optim.lr_scheduler.StepLR(opt, step_size=kw.get('step_size', 100), gamma=kw.get('gamma', 0.5))
+        if name == 'exponential':
+            return torch.optim.lr_scheduler.ExponentialLR(opt, gamma=kw.get('gamma', 0.99))
+        return None
+
+    # ---- training (solver_pt.py:191-277) ------------------------------------------------------------
+    def _save(self, path):
+        sd = self.model.state_dict()
+        torch.save(sd, path)
+        np.savez(path.replace('.pt', '.npz'), **{k: v.detach().cpu().numpy() for k, v in sd.items()})
+
+    def train(self):
+        n = self.train_output.shape[0]
+        bs = min(int(self.config.get('batch_size', 100)), n)
+        epochs = int(self.config['num_epochs'])
+        nb = max(1, int(np.ceil(n / bs)))
+        history = {'loss_train': [], 'loss_test': []}
+        os.makedirs(self.out_dir, exist_ok=True)
+        self.best_model_path = os.path.join(self.out_dir, 'best_model.pt')
+        for epoch in range(epochs):
+            self.model.train()
+            indices = np.random.permutation(n)                 # same seed on every rank -> same order
+            idx_dev = torch.as_tensor(indices, device=self.device)
+            stats = torch.zeros(3, dtype=torch.float64, device=self.device)   # sum of batch MSE, sse, sum y^2
+            for i in range(nb):
+                idx = idx_dev[i * bs:(i + 1) * bs]
+                gb = idx.numel()
+                lo, hi = shard_slice(gb, self.rank, self.world)
+                sel = idx[lo:hi]
+                flat = self.trainer.train_step(*[t[sel] for t in self.train_input], self.train_output[sel],
+                                               global_batch=gb)
+                tail = flat[self.trainer.numel:]
+                stats[0] += tail[0] / gb
+                stats[1] += tail[0]
+                stats[2] += tail[1]
+            s = stats.tolist()                                  # one host sync per epoch
+            avg_loss = s[0] / nb
+            avg_rel = np.sqrt(s[1]) / (np.sqrt(s[2]) + 1e-8)
+            history['loss_train'].append(avg_loss)
+            if avg_loss < self.best_loss:
+                self.best_loss = avg_loss
+                if self.config.get('if_save', True) and self.rank == 0:
+                    self._save(self.best_model_path)
+            if self.lr_scheduler is not None:
+                self.lr_scheduler.step()
+            if epoch % 10 == 0:
+                self.log(f"Epoch {epoch} | MSE: {avg_loss:.6e} | Rel_L2: {avg_rel:.4%}")
+        if self.config.get('if_save', True) and self.rank == 0:
+            self._save(os.path.join(self.out_dir, 'final_model.pt'))
+        return history
+
+    # ---- evaluation (solver_pt.py:279-329, utils/metrics.py:6-29) -----------------------------------------
+    def predict(self, inputs, batch_size=None):
+        bs = int(batch_size or self.config.get('batch_size', 100))
+        n = inputs[0].shape[0]
+        outs = []
+        self.model.eval()
+        with torch.no_grad():
+            for s in range(0, n, bs):
+                outs.append(self.model(*[t[s:s + bs] for t in inputs]))
+        return torch.cat(outs, dim=0)
+
+    def evaluate(self, history=None):
+        if self.best_model_path and os.path.exists(self.best_model_path):
+            sd = torch.load(self.best_model_path, map_location=self.device, weights_only=True)
+            self.model.load_state_dict(sd)
+        y_pred = self.predict(self.test_input, batch_size=self.config.get('eval_batch_size', 4096)).cpu().numpy()
+        y_true = self.test_output
+        diff = y_pred - y_true
+        metrics = {'MSE': float(np.mean(diff ** 2)), 'MAE': float(np.mean(np.abs(diff))),
+                   'Max_Error': float(np.max(np.abs(diff))),
+                   'rel_l2': float(np.linalg.norm(diff) / (np.linalg.norm(y_true) + 1e-8))}
+        if self.rank == 0:
+            os.makedirs(self.out_dir, exist_ok=True)
+            with open(os.path.join(self.out_dir, 'metric.json'), 'w') as f:
+                json.dump({'metrics': metrics, 'history': history}, f)
+        self.log(f"Test Relative L2 Error: {metrics['rel_l2']:.6f}")
+        return metrics
