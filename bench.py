@@ -133,49 +133,47 @@ def main():
         elapsed = float(t.item())
     samples_per_s = BATCH * world * args.steps / elapsed
 
-    # forward-only circuit evaluations/s (evaluation path), same batch
-    with torch.no_grad():
-        for i in range(5):
-            model(branch[:BATCH], trunk[:BATCH])
-        fence()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            model(branch[:BATCH], trunk[:BATCH])
-        fence()
-        fwd_elapsed = time.perf_counter() - t1
+    # forward-only circuit evaluations/s (evaluation path: qhea_model_forward), same batch
+    def fwd_only():
+        return _lib.model_forward(trainer.desc, branch[:BATCH], trunk[:BATCH], trainer.pflat)
+    for i in range(5):
+        fwd_only()
+    fence()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        fwd_only()
+    fence()
+    fwd_elapsed = time.perf_counter() - t1
     evals_per_s = BATCH * world * args.steps / fwd_elapsed
 
-    # dominant kernel (adjoint backward launch sequence), HIP events on the launch stream
+    # dominant kernel: the fused circuit kernel (forward sweep + MSE residual + adjoint reverse sweep) inside
+    # qhea_model_loss_grad; HIP events on the launch stream bracket prep + circuit + reduce (the rocprofv3
+    # summary under profiles/ gives the circuit kernel alone)
     cc = circuit_counts(N_QUBITS, NET)
     roof = None
     if rank == 0:
-        sh = model.quantum_layer._shape
-        x = torch.rand(BATCH, sh.E, device=dev, dtype=torch.float64) * 6 - 3
-        w = model.quantum_layer.ansatz_weights.detach()
-        g = torch.randn(BATCH, device=dev, dtype=torch.float64)
-        off, co = model.quantum_layer.ham_offset, model.quantum_layer.ham_coeff
-        _, st = _lib.hea_forward(sh, x, w, off, co, return_state=True)
+        yb = y[:BATCH].reshape(-1).contiguous()
+        def lg():
+            trainer.loss_and_grad(branch[:BATCH], trunk[:BATCH], yb, global_batch=BATCH * world)
         reps = max(20, min(args.steps, 200))
-        for _ in range(5):
-            _lib.hea_backward(sh, x, w, g, off, co, state=st)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for a, b in ev:
-            a.record(); _lib.hea_backward(sh, x, w, g, off, co, state=st); b.record()
-        torch.cuda.synchronize()
-        bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-        evf = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for a, b in evf:
-            a.record(); _lib.hea_forward(sh, x, w, off, co); b.record()
-        torch.cuda.synchronize()
-        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in evf]))
-        achieved = cc['bytes_bwd'] * BATCH / (bwd_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "qhea::bwd_kernel<5> (+prep, reduce)", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "launch_ms": bwd_ms, "algorithmic_bytes_per_launch": cc['bytes_bwd'] * BATCH,
-                "fwd_launch_ms": fwd_ms,
-                "fwd_achieved": cc['bytes_fwd'] * BATCH / (fwd_ms * 1e-3) / 1e9,
-                "note": "gate-streaming algorithmic bytes; the state is wave-resident so real HBM traffic is "
-                        "inputs+outputs only and frac may exceed 1 (see DESIGN.md)"}
+        def timed(fn):
+            for _ in range(5):
+                fn()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a, b in ev:
+                a.record(); fn(); b.record()
+            torch.cuda.synchronize()
+            return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        lg_ms = timed(lg)
+        fwd_ms = timed(fwd_only)
+        achieved = cc['bytes_train'] * BATCH / (lg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "qhea::bwd_kernel<5> fused fwd+adjoint (+prep, reduce launches)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "launch_ms": lg_ms, "algorithmic_bytes_per_launch": cc['bytes_train'] * BATCH,
+                "fwd_launch_ms": fwd_ms, "fwd_achieved": cc['bytes_fwd'] * BATCH / (fwd_ms * 1e-3) / 1e9,
+                "note": "gate-streaming algorithmic bytes (BASELINE.md section 2); the state is wave-resident, so "
+                        "real HBM traffic is inputs+outputs only and frac exceeds 1; the true bound is vector-ALU "
+                        "issue (see DESIGN.md)"}
 
     if rank == 0:
         cpu = None

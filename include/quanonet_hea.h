@@ -107,6 +107,73 @@ int qhea_backward(int n_qubits, int n_blocks,
                   double* grad_x /*DEVICE [B,E]*/, double* grad_w /*DEVICE [blk,3,n]*/,
                   void* workspace /*DEVICE*/, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Model-level entry points: the same kernels with the reference's classical pre/post-processing and
+ * the MSE loss fused in, so that one training step is three launches (prep, circuit, reduce) instead
+ * of ~35 framework kernels.  They replace, for the HIP backend,
+ *   QuanONetPT.forward / HEAQNNPT.forward            (core/models_pt.py:153-166, 205-213)
+ *   _TiledElementWise / _ScaleRepeat                  (core/models_pt.py:14-68)
+ *   nn.MSELoss + loss.backward() in the batch loop    (solvers/solver_pt.py:232-236)
+ *
+ * Parameters travel as ONE flat fp64 DEVICE vector in the order torch's nn.Module.parameters() /
+ * state_dict() yields for the reference classes (a module's own parameters before its children's):
+ *   QuanONet, trainable_freq=1: [bias (1) | branch_freq.weights (bd*n) | branch_freq.bias (bd*n) |
+ *                                trunk_freq.weights (td*n) | trunk_freq.bias (td*n) |
+ *                                quantum_layer.ansatz_weights (blk*3*n)]
+ *   QuanONet, trainable_freq=0: [bias | quantum_layer.ansatz_weights]
+ *   HEAQNN,   trainable_freq=1: [freq.weights (depth*n) | freq.bias (depth*n) | ansatz_weights]
+ *   HEAQNN,   trainable_freq=0: [ansatz_weights]
+ * and gradients come back in the same layout followed by two scalars [sse, sum_b y_b^2]
+ * (grad has qhea_model_param_count()+2 entries) so that a data-parallel caller needs exactly one
+ * SUM all-reduce per step.
+ * ------------------------------------------------------------------------------------------------ */
+#define QHEA_MODEL_QUANONET 0
+#define QHEA_MODEL_HEAQNN   1
+
+typedef struct qhea_model_desc {
+    int32_t model;            /* QHEA_MODEL_*                                                        */
+    int32_t n_qubits;
+    int32_t net[4];           /* QuanONet: (branch_depth, branch_ld, trunk_depth, trunk_ld);         */
+                              /* HEAQNN:   (depth, linear_depth, 0, 0)                               */
+    int32_t branch_in;        /* QuanONet: branch input features; HEAQNN: input features             */
+    int32_t trunk_in;         /* QuanONet: trunk input features;  HEAQNN: 0                          */
+    int32_t trainable_freq;   /* 1: _TiledElementWise (weights+bias in params); 0: _ScaleRepeat      */
+    int32_t reserved;
+    double  scale_coeff;      /* fixed scale when trainable_freq == 0                                */
+    double  ham_offset, ham_coeff;   /* H = offset + coeff * sum Z_i (ham_diag is passed per call)   */
+} qhea_model_desc;
+
+/* Number of trainable scalars for this model (layout above); negative QHEA_E* on a bad descriptor. */
+int64_t qhea_model_param_count(const qhea_model_desc* desc);
+
+/* DEVICE scratch bytes for the two calls below. */
+size_t qhea_model_workspace_bytes(const qhea_model_desc* desc, int64_t batch);
+
+/*
+ * pred[b] = model(branch[b], trunk[b])   (bias included for QuanONet).
+ * Replaces QuanONetPT.forward / HEAQNNPT.forward under torch.no_grad()
+ * (solvers/solver_pt.py:299-310, infer.py:274-289).  trunk is ignored (may be NULL) for HEAQNN.
+ */
+int qhea_model_forward(const qhea_model_desc* desc, int64_t batch,
+                       const double* branch /*DEVICE [B,branch_in]*/, const double* trunk /*DEVICE [B,trunk_in]*/,
+                       const double* params /*DEVICE flat*/, const double* ham_diag /*DEVICE [2^n] or NULL*/,
+                       double* pred /*DEVICE [B]*/, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * One fused loss + gradient evaluation:
+ *   pred_b = model(...);  loss contribution = (pred_b - y_b)^2 * inv_batch_total;
+ *   grad[0..P) = d/dparams sum_b (pred_b - y_b)^2 * inv_batch_total;  grad[P] = sum_b (pred_b-y_b)^2;
+ *   grad[P+1] = sum_b y_b^2.
+ * inv_batch_total = 1 / (GLOBAL batch size): a rank's shard passes the global size, and a SUM over
+ * ranks reproduces MSELoss(mean) gradients of the whole batch (solvers/solver_pt.py:232-236).
+ * pred may be NULL.
+ */
+int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch,
+                         const double* branch, const double* trunk, const double* y /*DEVICE [B]*/,
+                         const double* params, const double* ham_diag, double inv_batch_total,
+                         double* grad /*DEVICE [P+2]*/, double* pred /*DEVICE [B] or NULL*/,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

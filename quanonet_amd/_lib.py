@@ -14,7 +14,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libquanonet_hea.so')
 
 EXPORTS = ['qhea_version', 'qhea_strerror', 'qhea_device_count', 'qhea_workspace_bytes',
-           'qhea_forward', 'qhea_backward']
+           'qhea_forward', 'qhea_backward', 'qhea_model_param_count', 'qhea_model_workspace_bytes',
+           'qhea_model_forward', 'qhea_model_loss_grad']
+
+
+class ModelDesc(ctypes.Structure):
+    """Mirror of `qhea_model_desc` (include/quanonet_hea.h)."""
+    _fields_ = [('model', ctypes.c_int32), ('n_qubits', ctypes.c_int32), ('net', ctypes.c_int32 * 4),
+                ('branch_in', ctypes.c_int32), ('trunk_in', ctypes.c_int32),
+                ('trainable_freq', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('scale_coeff', ctypes.c_double), ('ham_offset', ctypes.c_double), ('ham_coeff', ctypes.c_double)]
+
+
+MODEL_QUANONET, MODEL_HEAQNN = 0, 1
 
 _lib = None
 
@@ -47,6 +59,16 @@ def load():
     lib.qhea_backward.argtypes = [ctypes.c_int, ctypes.c_int, i32p, i32p, ctypes.c_int64, dp, dp,
                                   ctypes.c_double, ctypes.c_double, dp, dp, dp, dp, dp, dp,
                                   vp, ctypes.c_size_t, vp]
+    mdp = ctypes.POINTER(ModelDesc)
+    lib.qhea_model_param_count.restype = ctypes.c_int64
+    lib.qhea_model_param_count.argtypes = [mdp]
+    lib.qhea_model_workspace_bytes.restype = ctypes.c_size_t
+    lib.qhea_model_workspace_bytes.argtypes = [mdp, ctypes.c_int64]
+    lib.qhea_model_forward.restype = ctypes.c_int
+    lib.qhea_model_forward.argtypes = [mdp, ctypes.c_int64, dp, dp, dp, dp, dp, vp, ctypes.c_size_t, vp]
+    lib.qhea_model_loss_grad.restype = ctypes.c_int
+    lib.qhea_model_loss_grad.argtypes = [mdp, ctypes.c_int64, dp, dp, dp, dp, dp, ctypes.c_double, dp, dp,
+                                         vp, ctypes.c_size_t, vp]
     _lib = lib
     return lib
 
@@ -146,3 +168,64 @@ def hea_backward(shape, x, w, g, ham_offset, ham_coeff, ham_diag=None, state=Non
                                _stream(x.device))
     _check(rc, 'qhea_backward')
     return (grad_x, grad_w, out) if want_out else (grad_x, grad_w)
+
+
+# ---------------------------------------------------------------------------------------------------
+# model-level (fused) calls
+# ---------------------------------------------------------------------------------------------------
+def make_model_desc(model, n_qubits, net_size, branch_in, trunk_in, trainable_freq, scale_coeff,
+                    ham_offset, ham_coeff):
+    net = list(net_size) + [0] * (4 - len(net_size))
+    d = ModelDesc(int(model), int(n_qubits), (ctypes.c_int32 * 4)(*[int(v) for v in net[:4]]), int(branch_in),
+                  int(trunk_in), 1 if trainable_freq else 0, 0, float(scale_coeff), float(ham_offset),
+                  float(ham_coeff))
+    return d
+
+
+def model_param_count(desc):
+    n = int(load().qhea_model_param_count(ctypes.byref(desc)))
+    if n < 0:
+        _check(n, 'qhea_model_param_count')
+    return n
+
+
+def model_forward(desc, branch, trunk, params, ham_diag=None, out=None):
+    lib = load()
+    B = branch.shape[0]
+    _dev_f64(branch, 'branch', (B, desc.branch_in))
+    if desc.model == MODEL_QUANONET:
+        _dev_f64(trunk, 'trunk', (B, desc.trunk_in))
+    _dev_f64(params, 'params')
+    _dev_f64(ham_diag, 'ham_diag', (1 << desc.n_qubits,))
+    pred = out if out is not None else torch.empty(B, dtype=torch.float64, device=branch.device)
+    nbytes = int(lib.qhea_model_workspace_bytes(ctypes.byref(desc), B))
+    ws = _workspace(branch.device, nbytes)
+    with torch.cuda.device(branch.device):
+        rc = lib.qhea_model_forward(ctypes.byref(desc), B, _ptr(branch), _ptr(trunk), _ptr(params), _ptr(ham_diag),
+                                    _ptr(pred), _ptr(ws), ws.numel(), _stream(branch.device))
+    _check(rc, 'qhea_model_forward')
+    return pred
+
+
+def model_loss_grad(desc, branch, trunk, y, params, inv_batch_total, grad, ham_diag=None, pred=None):
+    """Fills grad[P+2] = [d loss/d params | sse | sum y^2] for this shard; returns grad."""
+    lib = load()
+    B = branch.shape[0]
+    _dev_f64(branch, 'branch', (B, desc.branch_in))
+    if desc.model == MODEL_QUANONET:
+        _dev_f64(trunk, 'trunk', (B, desc.trunk_in))
+    _dev_f64(y, 'y')
+    if y.numel() != B:
+        raise QheaError(f"y has {y.numel()} elements, expected {B}")
+    _dev_f64(params, 'params')
+    _dev_f64(grad, 'grad')
+    _dev_f64(ham_diag, 'ham_diag', (1 << desc.n_qubits,))
+    _dev_f64(pred, 'pred', (B,))
+    nbytes = int(lib.qhea_model_workspace_bytes(ctypes.byref(desc), B))
+    ws = _workspace(branch.device, nbytes)
+    with torch.cuda.device(branch.device):
+        rc = lib.qhea_model_loss_grad(ctypes.byref(desc), B, _ptr(branch), _ptr(trunk), _ptr(y), _ptr(params),
+                                      _ptr(ham_diag), float(inv_batch_total), _ptr(grad), _ptr(pred),
+                                      _ptr(ws), ws.numel(), _stream(branch.device))
+    _check(rc, 'qhea_model_loss_grad')
+    return grad

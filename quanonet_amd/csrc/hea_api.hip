@@ -4,26 +4,34 @@
 
 namespace qhea {
 
-// U[s*n+q] = RY(w[s,2,q]) RZ(w[s,1,q]) RY(w[s,0,q]) as (ar,ai,br,bi);  cs[b,e] = (cos, sin)(x[b,e]/2)
-__global__ void prep_kernel(int n, int blk, const double* __restrict__ w, double4* __restrict__ U,
+// Gate table entry g = s*n+q (64 B): U = RY(w[s,2,q]) RZ(w[s,1,q]) RY(w[s,0,q]) = [[a,b],[-conj b,conj a]]
+// stored as two lane variants (ar, ai, br, bi) and (ar, -ai, -br, bi); `gates` points at entry -n
+// (n identity entries of padding on each side).  cs[b,e] = (cos, sin)(x[b,e]/2).
+__global__ void prep_kernel(int n, int blk, const double* __restrict__ w, double4* __restrict__ gates,
                             long BE, const double* __restrict__ x, double2* __restrict__ cs) {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long ng = (long)blk * n;
+    const long ng = (long)(blk + 2) * n;
     if (tid < ng) {
-        const int s = (int)(tid / n), q = (int)(tid % n);
-        const double* ws = w + (long)s * 3 * n;
-        double sa, ca, sb, cb, sc, cc;
-        sincos(0.5 * ws[q], &sa, &ca);
-        sincos(0.5 * ws[n + q], &sb, &cb);
-        sincos(0.5 * ws[2 * n + q], &sc, &cc);
-        // M = RZ(b) RY(a): M00 = e^{-ib/2} ca, M01 = -e^{-ib/2} sa, M10 = e^{+ib/2} sa, M11 = e^{+ib/2} ca
-        const double m00r = cb * ca, m00i = -sb * ca;
-        const double m01r = -cb * sa, m01i = sb * sa;
-        const double m10r = cb * sa, m10i = sb * sa;
-        const double m11r = cb * ca, m11i = sb * ca;
-        // U = RY(c) M: U00 = cc M00 - sc M10, U01 = cc M01 - sc M11
-        U[tid] = make_double4(cc * m00r - sc * m10r, cc * m00i - sc * m10i,
+        const long g = tid - n;                       // real gate index, or padding
+        double4 v0 = make_double4(1.0, 0.0, 0.0, 0.0);
+        if (g >= 0 && g < (long)blk * n) {
+            const int s = (int)(g / n), q = (int)(g % n);
+            const double* ws = w + (long)s * 3 * n;
+            double sa, ca, sb, cb, sc, cc;
+            sincos(0.5 * ws[q], &sa, &ca);
+            sincos(0.5 * ws[n + q], &sb, &cb);
+            sincos(0.5 * ws[2 * n + q], &sc, &cc);
+            // M = RZ(b) RY(a): M00 = e^{-ib/2} ca, M01 = -e^{-ib/2} sa, M10 = e^{+ib/2} sa, M11 = e^{+ib/2} ca
+            const double m00r = cb * ca, m00i = -sb * ca;
+            const double m01r = -cb * sa, m01i = sb * sa;
+            const double m10r = cb * sa, m10i = sb * sa;
+            const double m11r = cb * ca, m11i = sb * ca;
+            // U = RY(c) M: U00 = cc M00 - sc M10, U01 = cc M01 - sc M11
+            v0 = make_double4(cc * m00r - sc * m10r, cc * m00i - sc * m10i,
                               cc * m01r - sc * m11r, cc * m01i - sc * m11i);
+        }
+        gates[2 * tid] = v0;
+        gates[2 * tid + 1] = make_double4(v0.x, -v0.y, -v0.z, v0.w);
     } else if (tid - ng < BE) {
         const long t = tid - ng;
         double s, c;
@@ -34,27 +42,47 @@ __global__ void prep_kernel(int n, int blk, const double* __restrict__ w, double
 
 // grad_w[s,{0,1,2},q] from the per-wave (X,Y,Z) partial sums.
 //   g_c = Y;  g_b = cos(c) Z + sin(c) X;  g_a = cos(b) Y - sin(b) cos(c) X + sin(b) sin(c) Z
-// One thread per (s, q); waves are summed in index order (deterministic).
-__global__ void reduce_kernel(int n, int blk, int kw, long nwaves, const double* __restrict__ partial,
-                              const double* __restrict__ w, double* __restrict__ grad_w) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (long)blk * n) return;
-    const int s = (int)(tid / n), q = (int)(tid % n);
-    const double* p = partial + (long)s * kw + 3 * q;
-    const long stride = (long)blk * kw;
-    double X = 0.0, Y = 0.0, Z = 0.0;
-    for (long wv = 0; wv < nwaves; ++wv) {
-        X += p[0]; Y += p[1]; Z += p[2];
-        p += stride;
+// Block = 64 consecutive partial columns x 16 wave slices; every sum runs in a fixed order
+// (slice-strided over waves, then slices 0..15), so the result is bitwise reproducible.
+constexpr int kRedSlices = 16;
+__global__ __launch_bounds__(64 * kRedSlices) void reduce_kernel(int n, int blk, int kw, long nwaves,
+                                                                 const double* __restrict__ partial,
+                                                                 const double* __restrict__ w,
+                                                                 double* __restrict__ grad_w) {
+    __shared__ double acc[kRedSlices][64];
+    const int j = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const long ncols = (long)blk * kw;
+    const long v = (long)blockIdx.x * 64 + j;
+    double sum = 0.0;
+    if (v < ncols) {
+        const double* p = partial + v + (long)slice * ncols;
+        const long stride = (long)kRedSlices * ncols;
+        for (long wv = slice; wv < nwaves; wv += kRedSlices, p += stride) sum += *p;
     }
-    const double* ws = w + (long)s * 3 * n;
-    double sb, cb, sc, cc;
-    sincos(ws[n + q], &sb, &cb);
-    sincos(ws[2 * n + q], &sc, &cc);
-    double* gs = grad_w + (long)s * 3 * n;
-    gs[2 * n + q] = Y;
-    gs[n + q] = cc * Z + sc * X;
-    gs[q] = cb * Y - sb * cc * X + sb * sc * Z;
+    acc[slice][j] = sum;
+    __syncthreads();
+    if (slice == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < kRedSlices; ++i) t += acc[i][j];
+        acc[0][j] = t;
+    }
+    __syncthreads();
+    if (slice == 0 && v < ncols) {
+        const int s = (int)(v / kw), r = (int)(v % kw);
+        if (r < 3 * n && r % 3 == 0) {
+            const int q = r / 3;
+            const double X = acc[0][j], Y = acc[0][j + 1], Z = acc[0][j + 2];
+            const double* ws = w + (long)s * 3 * n;
+            double sb, cb, sc, cc;
+            sincos(ws[n + q], &sb, &cb);
+            sincos(ws[2 * n + q], &sc, &cc);
+            double* gs = grad_w + (long)s * 3 * n;
+            gs[2 * n + q] = Y;
+            gs[n + q] = cc * Z + sc * X;
+            gs[q] = cb * Y - sb * cc * X + sb * sc * Z;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -100,7 +128,7 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     const long nwg = (L.nwaves + kWaves - 1) / kWaves;
     L.nwaves = nwg * kWaves;                       // padding waves write zeros
     size_t p = 0;
-    L.off_U = p;    p = align_up(p + (size_t)sh.blk * n * sizeof(double4));
+    L.off_U = p;    p = align_up(p + (size_t)(sh.blk + 2) * n * kGateBytes);
     L.off_cs = p;   p = align_up(p + (size_t)B * sh.E * sizeof(double2));
     L.off_part = p; p = align_up(p + (size_t)L.nwaves * sh.blk * padded_3n(n) * sizeof(double));
     L.total = p;
@@ -109,13 +137,255 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
 
 int launch_prep(int n, const Shape& sh, int64_t B, const double* w, const double* x, char* ws, const Layout& L,
                 hipStream_t st) {
-    const long total = sh.blk * n + B * sh.E;
-    if (total == 0) return QHEA_OK;
+    const long total = (sh.blk + 2) * n + B * sh.E;
     const int threads = 256;
     const long blocks = (total + threads - 1) / threads;
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, n, (int)sh.blk, w,
                        reinterpret_cast<double4*>(ws + L.off_U), (long)(B * sh.E), x,
                        reinterpret_cast<double2*>(ws + L.off_cs));
+    return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// model-level (fused) path: frequency layers + sincos in prep, MSE residual in the circuit
+// kernel, every parameter gradient in one reduce launch
+// ---------------------------------------------------------------------------------------
+struct EncSeg {                 // x[b, col0 + e] = in[b, e % width] * w[e] + bias[e]   (or * scale when w == NULL)
+    const double* in; const double* w; const double* b;
+    double scale; int width; int ncols;
+};
+struct EncDesc { EncSeg seg[2]; };
+
+__global__ void prep_model_kernel(int n, int blk, const double* __restrict__ w, double4* __restrict__ gates,
+                                  long B, int E, EncDesc enc, double2* __restrict__ cs) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long ng = (long)(blk + 2) * n;
+    if (tid < ng) {
+        const long g = tid - n;
+        double4 v0 = make_double4(1.0, 0.0, 0.0, 0.0);
+        if (g >= 0 && g < (long)blk * n) {
+            const int s = (int)(g / n), q = (int)(g % n);
+            const double* ws = w + (long)s * 3 * n;
+            double sa, ca, sb, cb, sc, cc;
+            sincos(0.5 * ws[q], &sa, &ca);
+            sincos(0.5 * ws[n + q], &sb, &cb);
+            sincos(0.5 * ws[2 * n + q], &sc, &cc);
+            const double m00r = cb * ca, m00i = -sb * ca, m01r = -cb * sa, m01i = sb * sa;
+            const double m10r = cb * sa, m10i = sb * sa, m11r = cb * ca, m11i = sb * ca;
+            v0 = make_double4(cc * m00r - sc * m10r, cc * m00i - sc * m10i,
+                              cc * m01r - sc * m11r, cc * m01i - sc * m11i);
+        }
+        gates[2 * tid] = v0;
+        gates[2 * tid + 1] = make_double4(v0.x, -v0.y, -v0.z, v0.w);
+    } else if (tid - ng < B * E) {
+        const long t = tid - ng;
+        const long b = t / E;
+        int e = (int)(t % E);
+        const int si = e < enc.seg[0].ncols ? 0 : 1;
+        const EncSeg& sg = enc.seg[si];
+        if (si) e -= enc.seg[0].ncols;
+        const double v = sg.in[b * sg.width + e % sg.width];
+        const double x = sg.w ? v * sg.w[e] + sg.b[e] : v * sg.scale;
+        double s, c;
+        sincos(0.5 * x, &s, &c);
+        cs[t] = make_double2(c, s);
+    }
+}
+
+struct GradMap {                // where each gradient lives in the flat output
+    long off_ans, off_bias, off_sse;         // off_bias < 0: model has no bias
+    long off_w[2], off_b[2];                 // per encoding segment; < 0: not trainable
+};
+
+// Roles by block index: [0, nb_w) ansatz gradients from the (X,Y,Z) partials; [nb_w, nb_w+nb_x)
+// frequency-layer gradients from grad_x; last block: bias gradient, sse, sum y^2.
+__global__ __launch_bounds__(64 * kRedSlices) void reduce_model_kernel(
+        int n, int blk, int kw, long nwaves, const double* __restrict__ partial, const double* __restrict__ w,
+        long B, int E, EncDesc enc, const double* __restrict__ grad_x, const double* __restrict__ pred,
+        const double* __restrict__ y, double inv_bt, GradMap gm, int nb_w, int nb_x, double* __restrict__ grad) {
+    __shared__ double acc[kRedSlices][64];
+    __shared__ double acc2[kRedSlices][64];
+    const int j = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int bid = blockIdx.x;
+    if (bid < nb_w) {
+        const long ncols = (long)blk * kw;
+        const long v = (long)bid * 64 + j;
+        double sum = 0.0;
+        if (v < ncols) {
+            const double* p = partial + v + (long)slice * ncols;
+            const long stride = (long)kRedSlices * ncols;
+            for (long wv = slice; wv < nwaves; wv += kRedSlices, p += stride) sum += *p;
+        }
+        acc[slice][j] = sum;
+        __syncthreads();
+        if (slice == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < kRedSlices; ++i) t += acc[i][j];
+            acc[0][j] = t;
+        }
+        __syncthreads();
+        if (slice == 0 && v < ncols) {
+            const int s = (int)(v / kw), r = (int)(v % kw);
+            if (r < 3 * n && r % 3 == 0) {
+                const int q = r / 3;
+                const double X = acc[0][j], Y = acc[0][j + 1], Z = acc[0][j + 2];
+                const double* ws = w + (long)s * 3 * n;
+                double sb, cb, sc, cc;
+                sincos(ws[n + q], &sb, &cb);
+                sincos(ws[2 * n + q], &sc, &cc);
+                double* gs = grad + gm.off_ans + (long)s * 3 * n;
+                gs[2 * n + q] = Y;
+                gs[n + q] = cc * Z + sc * X;
+                gs[q] = cb * Y - sb * cc * X + sb * sc * Z;
+            }
+        }
+    } else if (bid < nb_w + nb_x) {
+        const int e = (bid - nb_w) * 64 + j;
+        double s0 = 0.0, s1 = 0.0;
+        int si = 0, ee = e;
+        if (e < E) {
+            si = e < enc.seg[0].ncols ? 0 : 1;
+            if (si) ee = e - enc.seg[0].ncols;
+            const EncSeg& sg = enc.seg[si];
+            const int ic = ee % sg.width;
+            for (long b = slice; b < B; b += kRedSlices) {
+                const double g = grad_x[b * E + e];
+                s0 += g;
+                s1 += g * sg.in[b * sg.width + ic];
+            }
+        }
+        acc[slice][j] = s0; acc2[slice][j] = s1;
+        __syncthreads();
+        if (slice == 0 && e < E && gm.off_w[si] >= 0) {
+            double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < kRedSlices; ++i) { t0 += acc[i][j]; t1 += acc2[i][j]; }
+            grad[gm.off_b[si] + ee] = t0;
+            grad[gm.off_w[si] + ee] = t1;
+        }
+    } else {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (long b = threadIdx.x; b < B; b += 64 * kRedSlices) {
+            const double r = pred[b] - y[b];
+            s0 += r * r; s1 += r; s2 += y[b] * y[b];
+        }
+        __shared__ double red[3][64 * kRedSlices];
+        red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+        __syncthreads();
+        for (int stride = 32 * kRedSlices; stride > 0; stride >>= 1) {
+            if ((int)threadIdx.x < stride) {
+                red[0][threadIdx.x] += red[0][threadIdx.x + stride];
+                red[1][threadIdx.x] += red[1][threadIdx.x + stride];
+                red[2][threadIdx.x] += red[2][threadIdx.x + stride];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            grad[gm.off_sse] = red[0][0];
+            grad[gm.off_sse + 1] = red[2][0];
+            if (gm.off_bias >= 0) grad[gm.off_bias] = 2.0 * inv_bt * red[1][0];
+        }
+    }
+}
+
+struct ModelInfo {
+    Shape sh;
+    int n = 0;
+    long enc_cols[2] = {0, 0};
+    int width[2] = {0, 0};
+    bool trainable = false, has_bias = false;
+    long P = 0, off_ans = 0, off_bias = -1, off_w[2] = {-1, -1}, off_b[2] = {-1, -1};
+};
+
+int model_info(const qhea_model_desc* d, ModelInfo& mi) {
+    if (!d) return QHEA_EINVAL;
+    const int n = d->n_qubits;
+    if (n < QHEA_MIN_QUBITS || n > QHEA_MAX_QUBITS) return QHEA_EINVAL;
+    for (int i = 0; i < 4; ++i) if (d->net[i] < 0) return QHEA_EINVAL;
+    mi.n = n;
+    mi.trainable = d->trainable_freq != 0;
+    long nb = 0;
+    int enc[1], ld[1];
+    (void)enc; (void)ld;
+    // block list: QuanONet = td x (n, tl) then bd x (n, bl) (core/quantum_circuits_tq.py:130-138); HEAQNN = depth x (n, ld)
+    int32_t* e = nullptr; int32_t* l = nullptr;
+    long Eb = 0, Et = 0;
+    if (d->model == QHEA_MODEL_QUANONET) {
+        if (d->branch_in <= 0 || d->trunk_in <= 0) return QHEA_EINVAL;
+        const int bd = d->net[0], bl = d->net[1], td = d->net[2], tl = d->net[3];
+        nb = (long)td + bd;
+        e = new int32_t[nb > 0 ? nb : 1]; l = new int32_t[nb > 0 ? nb : 1];
+        for (int i = 0; i < td; ++i) { e[i] = n; l[i] = tl; }
+        for (int i = 0; i < bd; ++i) { e[td + i] = n; l[td + i] = bl; }
+        Et = (long)td * n; Eb = (long)bd * n;
+        mi.enc_cols[0] = Et; mi.enc_cols[1] = Eb;           // x columns: trunk first (core/models_pt.py:164)
+        mi.width[0] = d->trunk_in; mi.width[1] = d->branch_in;
+        mi.has_bias = true;
+    } else if (d->model == QHEA_MODEL_HEAQNN) {
+        if (d->branch_in <= 0) return QHEA_EINVAL;
+        nb = d->net[0];
+        e = new int32_t[nb > 0 ? nb : 1]; l = new int32_t[nb > 0 ? nb : 1];
+        for (int i = 0; i < nb; ++i) { e[i] = n; l[i] = d->net[1]; }
+        mi.enc_cols[0] = (long)d->net[0] * n; mi.enc_cols[1] = 0;
+        mi.width[0] = d->branch_in; mi.width[1] = 1;
+        mi.has_bias = false;
+    } else {
+        return QHEA_EINVAL;
+    }
+    const int rc = make_shape(n, (int)nb, e, l, mi.sh);
+    delete[] e; delete[] l;
+    if (rc != QHEA_OK) return rc;
+    long p = 0;
+    if (mi.has_bias) { mi.off_bias = p; p += 1; }             // nn.Module order: own parameter `bias` first
+    if (mi.trainable) {
+        if (d->model == QHEA_MODEL_QUANONET) {               // then branch_freq, trunk_freq, quantum_layer
+            mi.off_w[1] = p; p += Eb; mi.off_b[1] = p; p += Eb;
+            mi.off_w[0] = p; p += Et; mi.off_b[0] = p; p += Et;
+        } else {
+            mi.off_w[0] = p; p += mi.enc_cols[0]; mi.off_b[0] = p; p += mi.enc_cols[0];
+        }
+    }
+    mi.off_ans = p; p += mi.sh.blk * 3 * n;
+    mi.P = p;
+    return QHEA_OK;
+}
+
+struct ModelLayout { Layout L; size_t off_gx, off_pred, total; };
+
+ModelLayout make_model_layout(const ModelInfo& mi, int64_t B) {
+    ModelLayout M{};
+    M.L = make_layout(mi.n, mi.sh, B);
+    size_t p = M.L.total;
+    M.off_gx = p;   p = align_up(p + (size_t)B * mi.sh.E * sizeof(double));
+    M.off_pred = p; p = align_up(p + (size_t)B * sizeof(double));
+    M.total = p;
+    return M;
+}
+
+EncDesc make_enc(const qhea_model_desc* d, const ModelInfo& mi, const double* branch, const double* trunk,
+                 const double* params) {
+    EncDesc enc{};
+    const double* in[2] = {d->model == QHEA_MODEL_QUANONET ? trunk : branch, branch};
+    for (int s = 0; s < 2; ++s) {
+        enc.seg[s].in = in[s];
+        enc.seg[s].width = mi.width[s];
+        enc.seg[s].ncols = (int)mi.enc_cols[s];
+        enc.seg[s].scale = d->scale_coeff;
+        enc.seg[s].w = (mi.trainable && mi.off_w[s] >= 0) ? params + mi.off_w[s] : nullptr;
+        enc.seg[s].b = (mi.trainable && mi.off_b[s] >= 0) ? params + mi.off_b[s] : nullptr;
+    }
+    return enc;
+}
+
+int launch_prep_model(const ModelInfo& mi, int64_t B, const double* params, const EncDesc& enc, char* ws,
+                      const Layout& L, hipStream_t st) {
+    const long total = (mi.sh.blk + 2) * mi.n + B * mi.sh.E;
+    const int threads = 256;
+    hipLaunchKernelGGL(prep_model_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0, st,
+                       mi.n, (int)mi.sh.blk, params + mi.off_ans, reinterpret_cast<double4*>(ws + L.off_U),
+                       (long)B, (int)mi.sh.E, enc, reinterpret_cast<double2*>(ws + L.off_cs));
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 
@@ -170,8 +440,9 @@ int qhea_forward(int n_qubits, int n_blocks, const int32_t* enc_per_block, const
     if (rc != QHEA_OK) return rc;
     const dim3 grid((unsigned)(L.nwaves / kWaves));
     const double2* cs = reinterpret_cast<const double2*>(ws + L.off_cs);
-    const double4* U = reinterpret_cast<const double4*>(ws + L.off_U);
-const FwdArgs fa{sh.runs, (long)batch, (int)sh.E, cs, U, ham_offset, ham_coeff, ham_diag, out, state_out};
+    const char* gates = ws + L.off_U;
+    const int gates_bytes = (int)((sh.blk + 2) * n_qubits * kGateBytes);
+const FwdArgs fa{sh.runs, (long)batch, (int)sh.E, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, out, state_out, nullptr};
     switch (n_qubits) {
 #define QHEA_CASE(NN) case NN: launch_fwd_##NN(grid, st, fa); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
@@ -204,10 +475,11 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
     if (rc != QHEA_OK) return rc;
     const dim3 grid((unsigned)(L.nwaves / kWaves));
     const double2* cs = reinterpret_cast<const double2*>(ws + L.off_cs);
-    const double4* U = reinterpret_cast<const double4*>(ws + L.off_U);
+    const char* gates = ws + L.off_U;
+    const int gates_bytes = (int)((sh.blk + 2) * n_qubits * kGateBytes);
     double* partial = reinterpret_cast<double*>(ws + L.off_part);
-const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, U, ham_offset, ham_coeff, ham_diag, g,
-                     state_in, out, grad_x, partial};
+const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, g,
+                     state_in, nullptr, nullptr, 0.0, out, grad_x, partial};
     switch (n_qubits) {
 #define QHEA_CASE(NN) case NN: launch_bwd_##NN(grid, st, ba); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
@@ -216,10 +488,97 @@ const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, U, ham_offset
     }
     if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
     if (sh.blk > 0) {
-        const long nthreads = sh.blk * n_qubits;
-        hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, st, n_qubits,
-                           (int)sh.blk, padded_3n(n_qubits), L.nwaves, partial, w, grad_w);
+        const long ncols = sh.blk * padded_3n(n_qubits);
+        hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(64 * kRedSlices), 0, st,
+                           n_qubits, (int)sh.blk, padded_3n(n_qubits), L.nwaves, partial, w, grad_w);
     }
+    return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+}
+
+int64_t qhea_model_param_count(const qhea_model_desc* desc) {
+    ModelInfo mi;
+    const int rc = model_info(desc, mi);
+    return rc == QHEA_OK ? (int64_t)mi.P : (int64_t)rc;
+}
+
+size_t qhea_model_workspace_bytes(const qhea_model_desc* desc, int64_t batch) {
+    ModelInfo mi;
+    if (model_info(desc, mi) != QHEA_OK || batch < 0) return 0;
+    return make_model_layout(mi, batch).total;
+}
+
+int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
+                       const double* params, const double* ham_diag, double* pred, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    ModelInfo mi;
+    int rc = model_info(desc, mi);
+    if (rc != QHEA_OK) return rc;
+    if (batch < 0) return QHEA_EINVAL;
+    if (batch == 0) return QHEA_OK;
+    if (!branch || !params || !pred || (desc->model == QHEA_MODEL_QUANONET && !trunk)) return QHEA_EINVAL;
+    const ModelLayout M = make_model_layout(mi, batch);
+    if (!workspace || workspace_bytes < M.total) return QHEA_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    const EncDesc enc = make_enc(desc, mi, branch, trunk, params);
+    rc = launch_prep_model(mi, batch, params, enc, ws, M.L, st);
+    if (rc != QHEA_OK) return rc;
+    const dim3 grid((unsigned)(M.L.nwaves / kWaves));
+    const FwdArgs fa{mi.sh.runs, (long)batch, (int)mi.sh.E, reinterpret_cast<const double2*>(ws + M.L.off_cs),
+                     ws + M.L.off_U, (int)((mi.sh.blk + 2) * mi.n * kGateBytes), desc->ham_offset, desc->ham_coeff,
+                     ham_diag, pred, nullptr, mi.has_bias ? params + mi.off_bias : nullptr};
+    switch (mi.n) {
+#define QHEA_CASE(NN) case NN: launch_fwd_##NN(grid, st, fa); break;
+        QHEA_FOR_EACH_N(QHEA_CASE)
+#undef QHEA_CASE
+        default: return QHEA_EUNSUPPORTED;
+    }
+    return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+}
+
+int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
+                         const double* y, const double* params, const double* ham_diag, double inv_batch_total,
+                         double* grad, double* pred, void* workspace, size_t workspace_bytes, void* stream) {
+    ModelInfo mi;
+    int rc = model_info(desc, mi);
+    if (rc != QHEA_OK) return rc;
+    if (batch < 0 || !grad) return QHEA_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (batch == 0) {
+        return hipMemsetAsync(grad, 0, sizeof(double) * (mi.P + 2), st) == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+    }
+    if (!branch || !params || !y || (desc->model == QHEA_MODEL_QUANONET && !trunk)) return QHEA_EINVAL;
+    const ModelLayout M = make_model_layout(mi, batch);
+    if (!workspace || workspace_bytes < M.total) return QHEA_EWORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    const EncDesc enc = make_enc(desc, mi, branch, trunk, params);
+    rc = launch_prep_model(mi, batch, params, enc, ws, M.L, st);
+    if (rc != QHEA_OK) return rc;
+    const dim3 grid((unsigned)(M.L.nwaves / kWaves));
+    double* gx = reinterpret_cast<double*>(ws + M.off_gx);
+    double* pr = pred ? pred : reinterpret_cast<double*>(ws + M.off_pred);
+    double* partial = reinterpret_cast<double*>(ws + M.L.off_part);
+    const BwdArgs ba{mi.sh.runs, (long)batch, (int)mi.sh.E, (int)mi.sh.blk,
+                     reinterpret_cast<const double2*>(ws + M.L.off_cs), ws + M.L.off_U,
+                     (int)((mi.sh.blk + 2) * mi.n * kGateBytes), desc->ham_offset, desc->ham_coeff, ham_diag,
+                     nullptr, nullptr, y, mi.has_bias ? params + mi.off_bias : nullptr, inv_batch_total,
+                     pr, gx, partial};
+    switch (mi.n) {
+#define QHEA_CASE(NN) case NN: launch_bwd_##NN(grid, st, ba); break;
+        QHEA_FOR_EACH_N(QHEA_CASE)
+#undef QHEA_CASE
+        default: return QHEA_EUNSUPPORTED;
+    }
+    if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
+    GradMap gm{};
+    gm.off_ans = mi.off_ans; gm.off_bias = mi.off_bias; gm.off_sse = mi.P;
+    for (int s = 0; s < 2; ++s) { gm.off_w[s] = mi.off_w[s]; gm.off_b[s] = mi.off_b[s]; }
+    const int kw = padded_3n(mi.n);
+    const int nb_w = (int)((mi.sh.blk * kw + 63) / 64);
+    const int nb_x = mi.trainable ? (int)((mi.sh.E + 63) / 64) : 0;
+    hipLaunchKernelGGL(reduce_model_kernel, dim3((unsigned)(nb_w + nb_x + 1)), dim3(64 * kRedSlices), 0, st, mi.n,
+                       (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
+                       gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad);
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 

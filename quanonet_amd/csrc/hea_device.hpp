@@ -32,6 +32,8 @@ namespace qhea {
 
 constexpr int kWaves = 4;              // waves per workgroup
 constexpr int kMaxRuns = 16;           // run-length-encoded (count, enc, ld) block list
+constexpr int kCsPerWave = 1024;       // wave-private LDS staging of (cos,sin) pairs: 16 KB per wave
+constexpr int kGateBytes = 64;         // one gate-table entry: 2 lane variants x (ar, s*ai, s*br, bi)
 
 struct Runs {
     int nruns;
@@ -49,6 +51,8 @@ struct Cfg {
     static constexpr int LANES = 1 << LB;           // lanes per sample
     static constexpr int KW = (3 * N <= 8) ? 8 : (3 * N <= 16) ? 16 : (3 * N <= 32) ? 32 : 64;  // padded 3N
     static constexpr int KX = (N <= 2) ? 2 : (N <= 4) ? 4 : (N <= 8) ? 8 : 16;                   // padded N
+    static constexpr int CAP = kCsPerWave / SPW;    // staged encoding columns per sample
+    static constexpr int UD = (N <= 6) ? N : 1;     // gate-coefficient prefetch distance (gates)
 };
 
 __host__ __device__ constexpr int padded_3n(int n) {
@@ -132,15 +136,14 @@ __device__ __forceinline__ void lane_reduce(double (&v)[K], int lane) {
 // ---------------------------------------------------------------------------------------
 // gate application on the wave-resident state
 // ---------------------------------------------------------------------------------------
-// SU(2) gate [[a,b],[-conj b, conj a]] on qubit Q.  The adjoint is the same call with
-// (ar,-ai,-br,-bi).
+// SU(2) gate [[a,b],[-conj b, conj a]] on qubit Q.  Coefficients come from the gate table already
+// specialised for this lane: u = (ar, s*ai, s*br, bi) with s = +1 when the lane's bit Q is 0 and -1
+// when it is 1 (for a register qubit s = +1).  The adjoint is the same call with (x,-y,-z,-w).
 template <int N, int Q>
 __device__ __forceinline__ void apply_su2(double (&re)[Cfg<N>::R], double (&im)[Cfg<N>::R],
-                                          double ar, double ai, double br, double bi, int lane) {
+                                          double ar, double sai, double sbr, double bi) {
     using C = Cfg<N>;
     if constexpr (Q < C::LB) {
-        const double s = ((lane >> Q) & 1) ? -1.0 : 1.0;
-        const double sai = s * ai, sbr = s * br;
 #pragma unroll
         for (int r = 0; r < C::R; ++r) {
             const double pr = re[r], pi = im[r];
@@ -150,6 +153,7 @@ __device__ __forceinline__ void apply_su2(double (&re)[Cfg<N>::R], double (&im)[
         }
     } else {
         constexpr int J = 1 << (Q - C::LB);
+        const double ai = sai, br = sbr;
 #pragma unroll
         for (int r0 = 0; r0 < C::R; ++r0) {
             if (r0 & J) continue;
@@ -321,35 +325,171 @@ __device__ __forceinline__ double ham_weight(int k, double off, double co, const
 }
 
 // ---------------------------------------------------------------------------------------
+// operand streams: gate coefficients (global, per-lane variant, rolling prefetch) and
+// per-sample RX (cos,sin) pairs (wave-private LDS window + one-block register prefetch)
+// ---------------------------------------------------------------------------------------
+// Gate table (built by prep_kernel): entry g = sub*N + q is 64 bytes = two double4 variants,
+// variant v for lanes whose bit q is v.  The table has N identity entries of padding on both
+// sides so that the prefetch may run past either end.  It is read with buffer loads: descriptor
+// and gate offset in SGPRs, the per-lane variant offset (0/32) in a VGPR -> no address arithmetic
+// on the vector ALU.  N <= 8: one register slot per qubit, refilled in place with the NEXT
+// sub-layer's coefficients right after use (a whole sub-layer of prefetch distance, no copies).
+// N >= 9: gates are long; the next gate's coefficients are fetched while the current one runs.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int N>
+struct GateStream {
+    using C = Cfg<N>;
+    static constexpr bool SLOTS = N <= 8;
+    double4 slot[SLOTS ? N : 1];
+    rsrc_t rsrc;
+    int soff;                       // wave-uniform byte offset of entry (sub, 0) from the table start
+    unsigned voff[N];               // per-lane variant offset (0 or 32) for each qubit
+
+    __device__ __forceinline__ void init(const char* table, int table_bytes, int lane) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(table), 0, table_bytes, 0x00020000);
+        static_for<0, N>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            voff[Q] = (Q < C::LB) ? (((unsigned)lane >> Q) & 1u) * 32u : 0u;
+        });
+    }
+    template <int G>                 // G = gate offset relative to (sub, 0); may be negative or >= N
+    __device__ __forceinline__ double4 load() const {
+        constexpr int Q = ((G % N) + N) % N;
+        const int so = soff + G * kGateBytes;
+        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[Q], so, 0);
+        const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[Q], so + 16, 0);
+        double4 r;
+        r.x = __hiloint2double((int)lo.y, (int)lo.x); r.y = __hiloint2double((int)lo.w, (int)lo.z);
+        r.z = __hiloint2double((int)hi.y, (int)hi.x); r.w = __hiloint2double((int)hi.w, (int)hi.z);
+        return r;
+    }
+    // position at sub-layer `sub` for a forward (first gate (sub,0)) or reverse (first gate (sub,N-1)) walk
+    template <bool FWD>
+    __device__ __forceinline__ void prime(int sub) {
+        soff = (sub + 1) * N * kGateBytes;            // +1: front padding
+        if constexpr (SLOTS) {
+            static_for<0, N>([&](auto q) { slot[decltype(q)::value] = load<decltype(q)::value>(); });
+        } else {
+            slot[0] = FWD ? load<0>() : load<N - 1>();
+        }
+    }
+    // use: u = gs.cur<FWD,Q>(); ...apply...; gs.done<FWD,Q>();
+    template <bool FWD, int Q>
+    __device__ __forceinline__ double4 cur() {
+        if constexpr (SLOTS) {
+            return slot[Q];
+        } else {
+            const double4 u = slot[0];
+            slot[0] = FWD ? load<Q + 1>() : load<Q - 1>();
+            return u;
+        }
+    }
+    template <bool FWD, int Q>
+    __device__ __forceinline__ void done() {
+        if constexpr (SLOTS) slot[Q] = FWD ? load<Q + N>() : load<Q - N>();
+    }
+    template <bool FWD>
+    __device__ __forceinline__ void advance() { soff += (FWD ? N : -N) * kGateBytes; }
+};
+
+template <int N>
+struct CsStream {
+    using C = Cfg<N>;
+    double2* lds;                   // wave-private region of kCsPerWave entries
+    const double2* src;             // global row of this lane's sample: cs + b*E
+    int E, klow, srow, lo, hi;      // staged column window [lo,hi) (wave-uniform)
+    double2 nxt[N];                 // register prefetch of the next block's first RX chunk
+
+    __device__ __forceinline__ void init(double2* lds_wave, const double2* cs, long b, int E_, int lane) {
+        lds = lds_wave; src = cs + b * E_; E = E_;
+        klow = lane & (C::LANES - 1);
+        srow = (lane >> C::LB) * C::CAP;
+        lo = hi = 0;
+    }
+    // every sample's LANES lanes stage that sample's columns [c0, c0+len): 8 loads in flight per lane
+    __device__ __forceinline__ void refill(int c0) {
+        const int len = (E - c0) < C::CAP ? (E - c0) : C::CAP;
+        constexpr int BATCH = 8;
+        for (int e0 = 0; e0 < len; e0 += BATCH * C::LANES) {
+            double2 t[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int e = e0 + i * C::LANES + klow;
+                t[i] = src[c0 + (e < len ? e : len - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int e = e0 + i * C::LANES + klow;
+                if (e < len) lds[srow + e] = t[i];
+            }
+        }
+        lo = c0; hi = c0 + len;
+    }
+    // make columns [c, c+m) resident; FWD windows start at c, reverse windows end at c+m
+    template <bool FWD>
+    __device__ __forceinline__ void need(int c, int m) {
+        c = __builtin_amdgcn_readfirstlane(c);
+        m = __builtin_amdgcn_readfirstlane(m);
+        if (c < __builtin_amdgcn_readfirstlane(lo) || c + m > __builtin_amdgcn_readfirstlane(hi)) {
+            int c0 = c;
+            if (!FWD) { c0 = c + m - C::CAP; if (c0 < 0) c0 = 0; }
+            refill(c0);
+        }
+    }
+    __device__ __forceinline__ double2 at(int c) const { return lds[srow + (c - lo)]; }
+    // nxt[q] = (cos,sin) of column c+q; entries past the block (or past E) are staged garbage, never used
+    template <bool FWD>
+    __device__ __forceinline__ void prefetch(int c) {
+        if (c >= E) return;
+        const int m = (E - c) < N ? (E - c) : N;
+        need<FWD>(c, m);
+        const double2* p = lds + srow + (c - lo);
+        static_for<0, N>([&](auto q) { nxt[decltype(q)::value] = p[decltype(q)::value]; });
+    }
+};
+
+// ---------------------------------------------------------------------------------------
 // forward sweep (shared by the forward and backward kernels)
 // ---------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void forward_sweep(double (&re)[Cfg<N>::R], double (&im)[Cfg<N>::R],
-                                              const Runs& runs, const double2* __restrict__ cs_b,
-                                              const double4* __restrict__ U, int lane, int ring_fwd) {
+                                              const Runs& runs, CsStream<N>& csx, GateStream<N>& gs,
+                                              int lane, int ring_fwd) {
     using C = Cfg<N>;
 #pragma unroll
     for (int r = 0; r < C::R; ++r) { re[r] = 0.0; im[r] = 0.0; }
     if ((lane & (C::LANES - 1)) == 0) re[0] = 1.0;
-    int col = 0, sub = 0;
+    int col = 0;
+    gs.template prime<true>(0);
+    csx.template prefetch<true>(0);
     for (int ri = 0; ri < runs.nruns; ++ri) {
         const int ne = runs.enc[ri], nld = runs.ld[ri];
         for (int rep = 0; rep < runs.count[ri]; ++rep) {
-            for (int j0 = 0; j0 < ne; j0 += N) {
+            static_for<0, N>([&](auto q) {
+                constexpr int Q = decltype(q)::value;
+                if (Q < ne) apply_rx<N, Q>(re, im, csx.nxt[Q].x, csx.nxt[Q].y);
+            });
+            for (int j0 = N; j0 < ne; j0 += N) {          // more encodings than wires (not used by the reference)
+                const int m = (ne - j0) < N ? (ne - j0) : N;
+                csx.template need<true>(col + j0, m);
                 static_for<0, N>([&](auto q) {
-                    if (j0 + decltype(q)::value < ne) {
-                        const double2 c = cs_b[col + j0 + decltype(q)::value];
-                        apply_rx<N, decltype(q)::value>(re, im, c.x, c.y);
-                    }
+                    constexpr int Q = decltype(q)::value;
+                    if (Q < m) { const double2 c = csx.at(col + j0 + Q); apply_rx<N, Q>(re, im, c.x, c.y); }
                 });
             }
             col += ne;
-            for (int l = 0; l < nld; ++l, ++sub) {
-                const double4* __restrict__ Us = U + (long)sub * N;
+            if (nld == 0) csx.template prefetch<true>(col);
+            for (int l = 0; l < nld; ++l) {
                 static_for<0, N>([&](auto q) {
-                    const double4 u = Us[decltype(q)::value];
-                    apply_su2<N, decltype(q)::value>(re, im, u.x, u.y, u.z, u.w, lane);
+                    constexpr int Q = decltype(q)::value;
+                    const double4 u = gs.template cur<true, Q>();
+                    apply_su2<N, Q>(re, im, u.x, u.y, u.z, u.w);
+                    gs.template done<true, Q>();
                 });
+                gs.template advance<true>();
+                if (l == nld - 1) csx.template prefetch<true>(col);
                 apply_ring<N, false>(re, im, lane, ring_fwd);
             }
         }
@@ -362,22 +502,30 @@ __device__ __forceinline__ void forward_sweep(double (&re)[Cfg<N>::R], double (&
 template <int N>
 __global__ __launch_bounds__(kWaves * 64) void fwd_kernel(Runs runs, long B, int E,
                                                           const double2* __restrict__ cs,
-                                                          const double4* __restrict__ U,
+                                                          const char* __restrict__ gates, int gates_bytes,
                                                           double off, double co,
                                                           const double* __restrict__ diag,
                                                           double* __restrict__ out,
-                                                          double* __restrict__ state_out) {
+                                                          double* __restrict__ state_out,
+                                                          const double* __restrict__ bias) {
     using C = Cfg<N>;
+    __shared__ double2 cs_lds[kWaves * kCsPerWave + 16];   // +16: slack for the unclamped prefetch
     const int lane = threadIdx.x & 63;
-    const long wave = (long)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const int wib = threadIdx.x >> 6;
+    const long wave = (long)blockIdx.x * kWaves + wib;
     const long b_raw = wave * C::SPW + (lane >> C::LB);
     const bool valid = b_raw < B;
     const long b = valid ? b_raw : B - 1;
     const int klow = lane & (C::LANES - 1);
     const int ring_fwd = ring_source<N < 6 ? N : 6>(lane, false);
 
+    CsStream<N> csx;
+    csx.init(cs_lds + wib * kCsPerWave, cs, b, E, lane);
+    GateStream<N> gs;
+    gs.init(gates, gates_bytes, lane);
+
     double re[C::R], im[C::R];
-    forward_sweep<N>(re, im, runs, cs + b * E, U, lane, ring_fwd);
+    forward_sweep<N>(re, im, runs, csx, gs, lane, ring_fwd);
 
     double acc = 0.0;
 #pragma unroll
@@ -391,30 +539,39 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_kernel(Runs runs, long B, int
     }
     double v[1] = {acc};
     lane_reduce<1, C::LB>(v, lane);
-    if (valid && klow == 0) out[b] = v[0];
+    if (valid && klow == 0) out[b] = v[0] + (bias ? bias[0] : 0.0);
 }
 
 template <int N>
 __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int E, int blk,
                                                           const double2* __restrict__ cs,
-                                                          const double4* __restrict__ U,
+                                                          const char* __restrict__ gates, int gates_bytes,
                                                           double off, double co,
                                                           const double* __restrict__ diag,
                                                           const double* __restrict__ g,
                                                           const double* __restrict__ state_in,
+                                                          const double* __restrict__ y,
+                                                          const double* __restrict__ bias,
+                                                          double inv_bt,
                                                           double* __restrict__ out,
                                                           double* __restrict__ grad_x,
                                                           double* __restrict__ partial) {
     using C = Cfg<N>;
+    __shared__ double2 cs_lds[kWaves * kCsPerWave + 16];   // +16: slack for the unclamped prefetch
     const int lane = threadIdx.x & 63;
-    const long wave = (long)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const int wib = threadIdx.x >> 6;
+    const long wave = (long)blockIdx.x * kWaves + wib;
     const long b_raw = wave * C::SPW + (lane >> C::LB);
     const bool valid = b_raw < B;
     const long b = valid ? b_raw : B - 1;
     const int klow = lane & (C::LANES - 1);
     const int ring_fwd = ring_source<N < 6 ? N : 6>(lane, false);
     const int ring_rev = ring_source<N < 6 ? N : 6>(lane, true);
-    const double2* __restrict__ cs_b = cs + b * E;
+
+    CsStream<N> csx;
+    csx.init(cs_lds + wib * kCsPerWave, cs, b, E, lane);
+    GateStream<N> gs;
+    gs.init(gates, gates_bytes, lane);
 
     double pr[C::R], pi[C::R], lr[C::R], li[C::R];
     if (state_in) {
@@ -424,84 +581,122 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
             pr[r] = a.x; pi[r] = a.y;
         }
     } else {
-        forward_sweep<N>(pr, pi, runs, cs_b, U, lane, ring_fwd);
+        forward_sweep<N>(pr, pi, runs, csx, gs, lane, ring_fwd);
     }
 
-    const double gb = valid ? g[b] : 0.0;      // padding lanes carry lambda = 0: no gradient contribution
+    // upstream weight: given (g), or the fused MSE residual 2 (out + bias - y) / batch_total when y != NULL
     double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < C::R; ++r)
+        acc += ham_weight<N>((r << C::LB) | klow, off, co, diag) * (pr[r] * pr[r] + pi[r] * pi[r]);
+    double gb;
+    if (y || out) {
+        double v[1] = {acc};
+        lane_reduce<1, C::LB>(v, lane);                      // butterfly: every lane of the sample gets the sum
+        const double pred = v[0] + (bias ? bias[0] : 0.0);
+        if (out && valid && klow == 0) out[b] = pred;
+        gb = y ? 2.0 * (pred - y[b]) * inv_bt : g[b];
+    } else {
+        gb = g[b];
+    }
+    if (!valid) gb = 0.0;                                    // padding lanes carry lambda = 0: no gradient contribution
 #pragma unroll
     for (int r = 0; r < C::R; ++r) {
         const double h = ham_weight<N>((r << C::LB) | klow, off, co, diag);
-        acc += h * (pr[r] * pr[r] + pi[r] * pi[r]);
         lr[r] = gb * h * pr[r];
         li[r] = gb * h * pi[r];
-    }
-    if (out) {
-        double v[1] = {acc};
-        lane_reduce<1, C::LB>(v, lane);
-        if (valid && klow == 0) out[b] = v[0];
     }
 
     double* __restrict__ part_w = partial + wave * (long)blk * C::KW;
     int col = E, sub = blk;
+    gs.template prime<false>(blk - 1);
     for (int ri = runs.nruns - 1; ri >= 0; --ri) {
         const int ne = runs.enc[ri], nld = runs.ld[ri];
+        const bool one_chunk = ne <= N;
         for (int rep = 0; rep < runs.count[ri]; ++rep) {
-            for (int l = 0; l < nld; ++l) {
+            for (int l = nld - 1; l >= 0; --l) {
                 --sub;
+                if (l == 0 && one_chunk && ne > 0) csx.template prefetch<false>(col - ne);
                 apply_ring<N, true>(pr, pi, lane, ring_rev);
                 apply_ring<N, true>(lr, li, lane, ring_rev);
-                const double4* __restrict__ Us = U + (long)sub * N;
                 double acc3[C::KW];
 #pragma unroll
                 for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
                 static_rfor<0, N>([&](auto q) {
-                    const double4 u = Us[decltype(q)::value];
-                    pauli_inner<N, decltype(q)::value>(pr, pi, lr, li, lane, acc3[3 * decltype(q)::value], acc3[3 * decltype(q)::value + 1],
-                                            acc3[3 * decltype(q)::value + 2]);
-                    apply_su2<N, decltype(q)::value>(pr, pi, u.x, -u.y, -u.z, -u.w, lane);
-                    apply_su2<N, decltype(q)::value>(lr, li, u.x, -u.y, -u.z, -u.w, lane);
+                    constexpr int Q = decltype(q)::value;
+                    const double4 u = gs.template cur<false, Q>();
+                    pauli_inner<N, Q>(pr, pi, lr, li, lane, acc3[3 * Q], acc3[3 * Q + 1], acc3[3 * Q + 2]);
+                    apply_su2<N, Q>(pr, pi, u.x, -u.y, -u.z, -u.w);
+                    apply_su2<N, Q>(lr, li, u.x, -u.y, -u.z, -u.w);
+                    gs.template done<false, Q>();
                 });
+                gs.template advance<false>();
                 lane_reduce<C::KW, 6>(acc3, lane);
                 if (lane < C::KW) part_w[(long)sub * C::KW + lane] = acc3[0];
             }
             col -= ne;
-            const int nchunks = (ne + N - 1) / N;
-            for (int ch = nchunks - 1; ch >= 0; --ch) {
-                const int j0 = ch * N;
-                double gx[C::KX];
+            if (one_chunk) {
+                if (ne > 0) {
+                    if (nld == 0) csx.template prefetch<false>(col);
+                    double gx[C::KX];
 #pragma unroll
-                for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
-                static_rfor<0, N>([&](auto q) {
-                    if (j0 + decltype(q)::value < ne) {
-                        const double2 c = cs_b[col + j0 + decltype(q)::value];
-                        gx[decltype(q)::value] = pauli_x_inner<N, decltype(q)::value>(pr, pi, lr, li);
-                        apply_rx<N, decltype(q)::value>(pr, pi, c.x, -c.y);
-                        apply_rx<N, decltype(q)::value>(lr, li, c.x, -c.y);
-                    }
-                });
-                lane_reduce<C::KX, C::LB>(gx, lane);
-                // lane with klow == j holds value j (KX <= 2^LB for every N)
-                if (valid && klow < N && j0 + klow < ne) grad_x[b * E + col + j0 + klow] = gx[0];
+                    for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
+                    static_rfor<0, N>([&](auto q) {
+                        constexpr int Q = decltype(q)::value;
+                        if (Q < ne) {
+                            gx[Q] = pauli_x_inner<N, Q>(pr, pi, lr, li);
+                            apply_rx<N, Q>(pr, pi, csx.nxt[Q].x, -csx.nxt[Q].y);
+                            apply_rx<N, Q>(lr, li, csx.nxt[Q].x, -csx.nxt[Q].y);
+                        }
+                    });
+                    lane_reduce<C::KX, C::LB>(gx, lane);
+                    // lane with klow == j holds value j (KX <= 2^LB for every N)
+                    if (valid && klow < ne) grad_x[b * E + col + klow] = gx[0];
+                }
+            } else {
+                const int nchunks = (ne + N - 1) / N;
+                for (int ch = nchunks - 1; ch >= 0; --ch) {
+                    const int j0 = ch * N;
+                    const int m = (ne - j0) < N ? (ne - j0) : N;
+                    csx.template need<false>(col + j0, m);
+                    double gx[C::KX];
+#pragma unroll
+                    for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
+                    static_rfor<0, N>([&](auto q) {
+                        constexpr int Q = decltype(q)::value;
+                        if (Q < m) {
+                            const double2 c = csx.at(col + j0 + Q);
+                            gx[Q] = pauli_x_inner<N, Q>(pr, pi, lr, li);
+                            apply_rx<N, Q>(pr, pi, c.x, -c.y);
+                            apply_rx<N, Q>(lr, li, c.x, -c.y);
+                        }
+                    });
+                    lane_reduce<C::KX, C::LB>(gx, lane);
+                    if (valid && klow < m) grad_x[b * E + col + j0 + klow] = gx[0];
+                }
             }
         }
     }
 }
 
-
 // ---------------------------------------------------------------------------------------
 // launch entry points; one translation unit per qubit count (hea_inst.hip, -DQHEA_N=n)
 // ---------------------------------------------------------------------------------------
 struct FwdArgs {
-    Runs runs; long B; int E; const double2* cs; const double4* U; double off, co;
-    const double* diag; double* out; double* state_out;
+    Runs runs; long B; int E; const double2* cs; const char* gates; int gates_bytes; double off, co;
+    const double* diag; double* out; double* state_out; const double* bias;
 };
 struct BwdArgs {
-    Runs runs; long B; int E; int blk; const double2* cs; const double4* U; double off, co;
-    const double* diag; const double* g; const double* state_in; double* out; double* grad_x; double* partial;
+    Runs runs; long B; int E; int blk; const double2* cs; const char* gates; int gates_bytes; double off, co;
+    const double* diag; const double* g; const double* state_in; const double* y; const double* bias; double inv_bt;
+    double* out; double* grad_x; double* partial;
 };
 
+#ifdef QHEA_SUBSET      // development builds: -D'QHEA_SUBSET(X)=X(2) X(5)' links only those qubit counts
+#define QHEA_FOR_EACH_N(X) QHEA_SUBSET(X)
+#else
 #define QHEA_FOR_EACH_N(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#endif
 #define QHEA_DECLARE(NN)                                              \
     void launch_fwd_##NN(dim3 grid, hipStream_t st, const FwdArgs& a); \
     void launch_bwd_##NN(dim3 grid, hipStream_t st, const BwdArgs& a);

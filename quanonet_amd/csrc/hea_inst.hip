@@ -11,12 +11,12 @@
 namespace qhea {
 
 void QHEA_CAT(launch_fwd_, QHEA_N)(dim3 grid, hipStream_t st, const FwdArgs& a) {
-    hipLaunchKernelGGL(fwd_kernel<QHEA_N>, grid, dim3(kWaves * 64), 0, st, a.runs, a.B, a.E, a.cs, a.U, a.off,
-                       a.co, a.diag, a.out, a.state_out);
+    hipLaunchKernelGGL(fwd_kernel<QHEA_N>, grid, dim3(kWaves * 64), 0, st, a.runs, a.B, a.E, a.cs, a.gates, a.gates_bytes, a.off,
+                       a.co, a.diag, a.out, a.state_out, a.bias);
 }
 void QHEA_CAT(launch_bwd_, QHEA_N)(dim3 grid, hipStream_t st, const BwdArgs& a) {
-    hipLaunchKernelGGL(bwd_kernel<QHEA_N>, grid, dim3(kWaves * 64), 0, st, a.runs, a.B, a.E, a.blk, a.cs, a.U,
-                       a.off, a.co, a.diag, a.g, a.state_in, a.out, a.grad_x, a.partial);
+    hipLaunchKernelGGL(bwd_kernel<QHEA_N>, grid, dim3(kWaves * 64), 0, st, a.runs, a.B, a.E, a.blk, a.cs, a.gates, a.gates_bytes,
+                       a.off, a.co, a.diag, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out, a.grad_x, a.partial);
 }
 
 }  // namespace qhea

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .circuit import build_quanonet_hip, build_heaqnn_hip
 
 HIP_BACKENDS = ('hip', 'mi355x', 'torchquantum')   # 'torchquantum' accepted as an alias: drop-in
@@ -85,6 +86,14 @@ class QuanONetPT(nn.Module):
             branch_input_size=branch_input_size, trunk_input_size=trunk_input_size, dtype=dtype)
         self.bias = nn.Parameter(torch.zeros(1, dtype=dtype))
 
+    def fused_desc(self):
+        """Descriptor for the model-level C ABI (qhea_model_*); parameter order == self.parameters()."""
+        q = self.quantum_layer
+        return _lib.make_model_desc(_lib.MODEL_QUANONET, self.num_qubits, self.net_size,
+                                    self.branch_freq.in_features, self.trunk_freq.in_features,
+                                    self.if_trainable_freq, getattr(self.branch_freq, 'scale', 0.0),
+                                    q.ham_offset, q.ham_coeff)
+
     def forward(self, branch_input, trunk_input):
         branch_enc = self.branch_freq(branch_input)
         trunk_enc = self.trunk_freq(trunk_input)
@@ -110,6 +119,12 @@ class HEAQNNPT(nn.Module):
         self.quantum_layer = _build_quantum_layer(
             quantum_backend, num_qubits, total_input_size=enc_size,
             net_size=net_size, ham_bound=ham_bound, ham_diag=ham_diag, dtype=dtype)
+
+    def fused_desc(self):
+        q = self.quantum_layer
+        return _lib.make_model_desc(_lib.MODEL_HEAQNN, self.num_qubits, self.net_size[:2], self.freq.in_features, 0,
+                                    self.if_trainable_freq, getattr(self.freq, 'scale', 0.0),
+                                    q.ham_offset, q.ham_coeff)
 
     def forward(self, x):
         return self.quantum_layer(self.freq(x))

@@ -29,21 +29,43 @@ def shard_slice(n_items, rank, world):
 
 
 class DataParallelTrainer:
-    def __init__(self, model, lr=1e-4, world_size=1, dist=None, optimizer='adam', optimizer_kwargs=None):
+    """
+    fused='auto': when the model is one of this package's QuanONetPT / HEAQNNPT (fp64, on a HIP
+    device) the step runs through the model-level C ABI (qhea_model_loss_grad: three launches);
+    otherwise through torch autograd on the module (HEACircuitHIP's autograd.Function).  Both paths
+    fill the same flat buffer, so the collective and the optimizer step are shared.
+    """
+
+    def __init__(self, model, lr=1e-4, world_size=1, dist=None, optimizer='adam', optimizer_kwargs=None,
+                 fused='auto'):
         self.model = model
         self.world = int(world_size)
         self.dist = dist
         self.params = [p for p in model.parameters() if p.requires_grad]
         p0 = self.params[0]
         self.numel = sum(p.numel() for p in self.params)
-        # flat gradient buffer; .grad of every parameter is a view into it (+2 logging scalars)
-        self.flat = torch.zeros(self.numel + 2, dtype=torch.float64, device=p0.device)
-        off = 0
         for p in self.params:
             if p.dtype != torch.float64:
                 raise ValueError("DataParallelTrainer expects float64 parameters (fp64 training path)")
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        # flat parameter vector (reference state_dict order) and flat gradient buffer (+2 logging scalars);
+        # every parameter / .grad becomes a view into them
+        self.pflat = torch.empty(self.numel, dtype=torch.float64, device=p0.device)
+        self.flat = torch.zeros(self.numel + 2, dtype=torch.float64, device=p0.device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.pflat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.pflat[off:off + n].view(p.shape)
+            p.grad = self.flat[off:off + n].view(p.shape)
+            off += n
+        self.desc = None
+        if fused and hasattr(model, 'fused_desc') and p0.is_cuda and len(self.params) == len(list(model.parameters())):
+            from . import _lib
+            desc = model.fused_desc()
+            if _lib.model_param_count(desc) == self.numel:
+                self.desc = desc
+        if fused is True and self.desc is None:
+            raise RuntimeError("fused training path requested but the model does not support it")
         kw = dict(optimizer_kwargs or {})
         opt_map = {'adam': torch.optim.Adam, 'adamw': torch.optim.AdamW, 'sgd': torch.optim.SGD,
                    'rmsprop': torch.optim.RMSprop}
@@ -55,26 +77,41 @@ class DataParallelTrainer:
             self.broadcast_parameters()
 
     def broadcast_parameters(self):
-        for p in self.params:
-            self.dist.broadcast(p.data, src=0)
+        self.dist.broadcast(self.pflat, src=0)
 
     def _forward(self, inputs):
         if isinstance(inputs, (tuple, list)):
             return self.model(*inputs)
         return self.model(inputs)
 
-    def train_step(self, *batch, global_batch=None):
-        """batch = (branch, trunk, y) or (x, y): this rank's shard.  Returns the flat buffer (device)."""
+    def _ham_diag(self):
+        q = getattr(self.model, 'quantum_layer', None)
+        return q.ham_diag if (q is not None and getattr(q, 'use_full_ham', False)) else None
+
+    def loss_and_grad(self, *batch, global_batch=None):
+        """Fill self.flat with this shard's [gradients | sse | sum y^2] (no collective, no update)."""
         *inputs, y = batch
         gb = float(global_batch if global_batch is not None else y.shape[0] * self.world)
-        self.flat.zero_()
-        pred = self._forward(inputs)
-        resid = pred - y.reshape(pred.shape)
-        sse = (resid * resid).sum()
-        (sse / gb).backward()
-        with torch.no_grad():
-            self.flat[self.numel] = sse
-            self.flat[self.numel + 1] = (y * y).sum()
+        if self.desc is not None:
+            from . import _lib
+            branch = inputs[0]
+            trunk = inputs[1] if len(inputs) > 1 else None
+            _lib.model_loss_grad(self.desc, branch, trunk, y.reshape(-1), self.pflat, 1.0 / gb, self.flat,
+                                 ham_diag=self._ham_diag())
+        else:
+            self.flat.zero_()
+            pred = self._forward(inputs)
+            resid = pred - y.reshape(pred.shape)
+            sse = (resid * resid).sum()
+            (sse / gb).backward()
+            with torch.no_grad():
+                self.flat[self.numel] = sse
+                self.flat[self.numel + 1] = (y * y).sum()
+        return self.flat
+
+    def train_step(self, *batch, global_batch=None):
+        """batch = (branch, trunk, y) or (x, y): this rank's shard.  Returns the flat buffer (device)."""
+        self.loss_and_grad(*batch, global_batch=global_batch)
         if self.world > 1:
             self.dist.all_reduce(self.flat)            # SUM; one latency-bound message (19 KB at Q5)
         self.optimizer.step()
@@ -212,9 +249,17 @@ class PTSolver:
         n = inputs[0].shape[0]
         outs = []
         self.model.eval()
+        tr = self.trainer
         with torch.no_grad():
             for s in range(0, n, bs):
-                outs.append(self.model(*[t[s:s + bs] for t in inputs]))
+                chunk = [t[s:s + bs] for t in inputs]
+                if tr.desc is not None:
+                    from . import _lib
+                    o = _lib.model_forward(tr.desc, chunk[0], chunk[1] if len(chunk) > 1 else None, tr.pflat,
+                                           ham_diag=tr._ham_diag())
+                    outs.append(o.unsqueeze(-1))
+                else:
+                    outs.append(self.model(*chunk))
         return torch.cat(outs, dim=0)
 
     def evaluate(self, history=None):

@@ -151,3 +151,75 @@ def test_model_grads_match_oracle(dev):
     xe = O.tiled_elementwise(xin, sd['freq.weights'], sd['freq.bias'])
     ref = O.hea_forward(4, O.block_configs_heaqnn(4, (3, 2)), xe, sd['quantum_layer.ansatz_weights'], *O.ham_params(4))
     np.testing.assert_allclose(o, ref, atol=TOL)
+
+
+@pytest.mark.parametrize('n,net,tf', [(5, (3, 2, 2, 1), True), (2, (5, 1, 5, 1), True), (5, (2, 2, 2, 2), False),
+                                      (8, (2, 1, 1, 2), True)])
+def test_fused_model_path_matches_oracle_and_autograd(dev, n, net, tf):
+    """qhea_model_loss_grad / qhea_model_forward == oracle == the autograd module path."""
+    from quanonet_amd.models import QuanONetPT
+    from quanonet_amd.solver import DataParallelTrainer
+    from quanonet_amd import _lib
+    torch.manual_seed(3)
+    b_in, t_in, B = 7, 2, 45
+    model = QuanONetPT(n, b_in, t_in, net, scale_coeff=0.1, if_trainable_freq=tf).to(dev)
+    rng = np.random.default_rng(n)
+    br = rng.normal(size=(B, b_in)); tr = rng.uniform(size=(B, t_in)); y = rng.normal(size=B)
+    if tf:
+        with torch.no_grad():
+            model.branch_freq.bias.copy_(_t(rng.normal(size=model.branch_freq.bias.shape), dev))
+            model.trunk_freq.bias.copy_(_t(rng.normal(size=model.trunk_freq.bias.shape), dev))
+            model.bias.fill_(0.3)
+    fused = DataParallelTrainer(model, lr=1e-3, fused=True)
+    flat = fused.loss_and_grad(_t(br, dev), _t(tr, dev), _t(y, dev), global_batch=2 * B).clone()
+    pred = _lib.model_forward(fused.desc, _t(br, dev), _t(tr, dev), fused.pflat).cpu().numpy()
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    if tf:
+        rl, rg, ro = O.quanonet_loss_and_grads(sd, br, tr, y, n, net, batch_total=2 * B)
+        ref = np.concatenate([rg[k].reshape(-1) for k, _ in model.named_parameters()])
+        np.testing.assert_allclose(pred, ro, rtol=0, atol=TOL)
+        np.testing.assert_allclose(flat[:-2].cpu().numpy(), ref, rtol=0, atol=TOL)
+        assert abs(flat[-2].item() - rl * 2 * B) < 1e-9
+    assert abs(flat[-1].item() - float((y ** 2).sum())) < 1e-9
+    # autograd path on the same module
+    auto = DataParallelTrainer(model, lr=1e-3, fused=False)
+    flat2 = auto.loss_and_grad(_t(br, dev), _t(tr, dev), _t(y, dev).unsqueeze(-1), global_batch=2 * B)
+    np.testing.assert_allclose(flat.cpu().numpy(), flat2.cpu().numpy(), rtol=0, atol=TOL)
+    with torch.no_grad():
+        p2 = model(_t(br, dev), _t(tr, dev))[:, 0].cpu().numpy()
+    np.testing.assert_allclose(pred, p2, rtol=0, atol=TOL)
+
+
+def test_fused_heaqnn_path(dev):
+    from quanonet_amd.models import HEAQNNPT
+    from quanonet_amd.solver import DataParallelTrainer
+    torch.manual_seed(4)
+    model = HEAQNNPT(5, 9, (3, 2), scale_coeff=0.1, if_trainable_freq=True).to(dev)
+    rng = np.random.default_rng(9)
+    x = rng.normal(size=(33, 9)); y = rng.normal(size=33)
+    fused = DataParallelTrainer(model, fused=True)
+    f1 = fused.loss_and_grad(_t(x, dev), _t(y, dev)).clone()
+    auto = DataParallelTrainer(model, fused=False)
+    f2 = auto.loss_and_grad(_t(x, dev), _t(y, dev).unsqueeze(-1))
+    np.testing.assert_allclose(f1.cpu().numpy(), f2.cpu().numpy(), rtol=0, atol=TOL)
+
+
+def test_training_reduces_loss_and_steps_are_deterministic(dev):
+    from quanonet_amd.models import QuanONetPT
+    from quanonet_amd.solver import DataParallelTrainer
+    rng = np.random.default_rng(0)
+    br = _t(rng.normal(size=(256, 6)), dev); tr = _t(rng.uniform(size=(256, 1)), dev)
+    y = torch.sin(3 * tr[:, 0]) * br[:, 0]
+    losses = []
+    for rep in range(2):
+        torch.manual_seed(0)
+        model = QuanONetPT(2, 6, 1, (3, 1, 3, 1), scale_coeff=0.1, if_trainable_freq=True).to(dev)
+        t = DataParallelTrainer(model, lr=5e-2)
+        hist = []
+        for it in range(60):
+            t.train_step(br, tr, y)
+            if it % 10 == 0:
+                hist.append(t.loss_scalars()[0])
+        losses.append(hist)
+    assert losses[0] == losses[1]                  # bitwise reproducible
+    assert losses[0][-1] < 0.7 * losses[0][0]
