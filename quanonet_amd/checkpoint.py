@@ -184,8 +184,7 @@ _MODEL_RE = re.compile(r'_(QuanONet|HEAQNN)_')
 
 def parse_experiment_dir(path):
     """Hyper-parameters encoded in an experiment directory name (infer.py:60-86)."""
-    name = path
-    if os.path.splitext(path)[1]:
+    if os.path.splitext(path)[1].lower() in ('.ckpt', '.npz', '.pt', '.pth'):
         name = os.path.basename(os.path.dirname(os.path.abspath(path)))
     else:
         name = os.path.basename(os.path.normpath(path))

@@ -40,39 +40,49 @@ __global__ void prep_kernel(int n, int blk, const double* __restrict__ w, double
     }
 }
 
-// grad_w[s,{0,1,2},q] from the per-wave (X,Y,Z) partial sums.
-//   g_c = Y;  g_b = cos(c) Z + sin(c) X;  g_a = cos(b) Y - sin(b) cos(c) X + sin(b) sin(c) Z
-// Block = 64 consecutive partial columns x 16 wave slices; every sum runs in a fixed order
-// (slice-strided over waves, then slices 0..15), so the result is bitwise reproducible.
-constexpr int kRedSlices = 16;
-__global__ __launch_bounds__(64 * kRedSlices) void reduce_kernel(int n, int blk, int kw, long nwaves,
-                                                                 const double* __restrict__ partial,
-                                                                 const double* __restrict__ w,
-                                                                 double* __restrict__ grad_w) {
-    __shared__ double acc[kRedSlices][64];
-    const int j = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const long ncols = (long)blk * kw;
-    const long v = (long)blockIdx.x * 64 + j;
-    double sum = 0.0;
-    if (v < ncols) {
-        const double* p = partial + v + (long)slice * ncols;
-        const long stride = (long)kRedSlices * ncols;
-        for (long wv = slice; wv < nwaves; wv += kRedSlices, p += stride) sum += *p;
+// Deterministic column sums of a row-major [rows, ncols] matrix: a block owns `cols` consecutive columns
+// (cols = max(16, kw), so a sub-layer's X,Y,Z triples never straddle blocks) and splits the rows over
+// kRedThreads/cols slices (8 independent loads in flight per thread); partial sums are combined in slice
+// order, so results are bitwise reproducible.
+constexpr int kRedThreads = 1024;
+__host__ __device__ constexpr int red_cols(int kw) { return kw < 16 ? 16 : kw; }
+
+__device__ __forceinline__ double slice_sum(const double* __restrict__ p, long rows, long stride_rows,
+                                            int slice, int nslices) {
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long r = slice;
+    const long step = (long)nslices * stride_rows;
+    const double* q = p + (long)slice * stride_rows;
+    for (; r + 7L * nslices < rows; r += 8L * nslices, q += 8 * step) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += q[i * step];
     }
-    acc[slice][j] = sum;
+    for (int i = 0; r < rows; r += nslices, q += step, ++i) a[i] += *q;
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+// grad_w[s,{0,1,2},q] from the per-wave (X,Y,Z) partial sums (column sums over waves of partial[wave][s][kw]).
+//   g_c = Y;  g_b = cos(c) Z + sin(c) X;  g_a = cos(b) Y - sin(b) cos(c) X + sin(b) sin(c) Z
+__device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw, long nwaves,
+                                                 const double* __restrict__ partial, const double* __restrict__ w,
+                                                 double* __restrict__ grad_w, double* acc /*[kRedThreads]*/) {
+    const int cols = red_cols(kw), nslices = kRedThreads / cols;
+    const int j = threadIdx.x % cols, slice = threadIdx.x / cols;
+    const long ncols = (long)blk * kw;
+    const long v = (long)bid * cols + j;
+    acc[slice * cols + j] = v < ncols ? slice_sum(partial + v, nwaves, ncols, slice, nslices) : 0.0;
     __syncthreads();
     if (slice == 0) {
         double t = 0.0;
-#pragma unroll
-        for (int i = 0; i < kRedSlices; ++i) t += acc[i][j];
-        acc[0][j] = t;
+        for (int i = 0; i < nslices; ++i) t += acc[i * cols + j];
+        acc[j] = t;
     }
     __syncthreads();
     if (slice == 0 && v < ncols) {
         const int s = (int)(v / kw), r = (int)(v % kw);
         if (r < 3 * n && r % 3 == 0) {
             const int q = r / 3;
-            const double X = acc[0][j], Y = acc[0][j + 1], Z = acc[0][j + 2];
+            const double X = acc[j], Y = acc[j + 1], Z = acc[j + 2];
             const double* ws = w + (long)s * 3 * n;
             double sb, cb, sc, cc;
             sincos(ws[n + q], &sb, &cb);
@@ -83,6 +93,14 @@ __global__ __launch_bounds__(64 * kRedSlices) void reduce_kernel(int n, int blk,
             gs[q] = cb * Y - sb * cc * X + sb * sc * Z;
         }
     }
+}
+
+__global__ __launch_bounds__(kRedThreads) void reduce_kernel(int n, int blk, int kw, long nwaves,
+                                                             const double* __restrict__ partial,
+                                                             const double* __restrict__ w,
+                                                             double* __restrict__ grad_w) {
+    __shared__ double acc[kRedThreads];
+    reduce_xyz_block(blockIdx.x, n, blk, kw, nwaves, partial, w, grad_w, acc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -199,93 +217,75 @@ struct GradMap {                // where each gradient lives in the flat output
 };
 
 // Roles by block index: [0, nb_w) ansatz gradients from the (X,Y,Z) partials; [nb_w, nb_w+nb_x)
-// frequency-layer gradients from grad_x; last block: bias gradient, sse, sum y^2.
-__global__ __launch_bounds__(64 * kRedSlices) void reduce_model_kernel(
+// frequency-layer gradients from grad_x (16 columns x 64 row slices per block); last block: bias gradient,
+// sse, sum y^2.
+constexpr int kFreqCols = 16, kFreqSlices = kRedThreads / kFreqCols;
+__global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         int n, int blk, int kw, long nwaves, const double* __restrict__ partial, const double* __restrict__ w,
         long B, int E, EncDesc enc, const double* __restrict__ grad_x, const double* __restrict__ pred,
         const double* __restrict__ y, double inv_bt, GradMap gm, int nb_w, int nb_x, double* __restrict__ grad) {
-    __shared__ double acc[kRedSlices][64];
-    __shared__ double acc2[kRedSlices][64];
-    const int j = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    __shared__ double acc[kRedThreads];
+    __shared__ double acc2[kRedThreads];
     const int bid = blockIdx.x;
     if (bid < nb_w) {
-        const long ncols = (long)blk * kw;
-        const long v = (long)bid * 64 + j;
-        double sum = 0.0;
-        if (v < ncols) {
-            const double* p = partial + v + (long)slice * ncols;
-            const long stride = (long)kRedSlices * ncols;
-            for (long wv = slice; wv < nwaves; wv += kRedSlices, p += stride) sum += *p;
-        }
-        acc[slice][j] = sum;
-        __syncthreads();
-        if (slice == 0) {
-            double t = 0.0;
-#pragma unroll
-            for (int i = 0; i < kRedSlices; ++i) t += acc[i][j];
-            acc[0][j] = t;
-        }
-        __syncthreads();
-        if (slice == 0 && v < ncols) {
-            const int s = (int)(v / kw), r = (int)(v % kw);
-            if (r < 3 * n && r % 3 == 0) {
-                const int q = r / 3;
-                const double X = acc[0][j], Y = acc[0][j + 1], Z = acc[0][j + 2];
-                const double* ws = w + (long)s * 3 * n;
-                double sb, cb, sc, cc;
-                sincos(ws[n + q], &sb, &cb);
-                sincos(ws[2 * n + q], &sc, &cc);
-                double* gs = grad + gm.off_ans + (long)s * 3 * n;
-                gs[2 * n + q] = Y;
-                gs[n + q] = cc * Z + sc * X;
-                gs[q] = cb * Y - sb * cc * X + sb * sc * Z;
-            }
-        }
+        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc);
     } else if (bid < nb_w + nb_x) {
-        const int e = (bid - nb_w) * 64 + j;
+        const int j = threadIdx.x % kFreqCols, slice = threadIdx.x / kFreqCols;
+        const int e = (bid - nb_w) * kFreqCols + j;
         double s0 = 0.0, s1 = 0.0;
         int si = 0, ee = e;
         if (e < E) {
             si = e < enc.seg[0].ncols ? 0 : 1;
             if (si) ee = e - enc.seg[0].ncols;
             const EncSeg& sg = enc.seg[si];
-            const int ic = ee % sg.width;
-            for (long b = slice; b < B; b += kRedSlices) {
-                const double g = grad_x[b * E + e];
+            const double* __restrict__ in = sg.in + ee % sg.width;
+            const double* __restrict__ gx = grad_x + e;
+            long b = slice;
+            for (; b + 3L * kFreqSlices < B; b += 4L * kFreqSlices) {
+                double g[4], v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    g[i] = gx[(b + (long)i * kFreqSlices) * E];
+                    v[i] = in[(b + (long)i * kFreqSlices) * sg.width];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { s0 += g[i]; s1 += g[i] * v[i]; }
+            }
+            for (; b < B; b += kFreqSlices) {
+                const double g = gx[b * E];
                 s0 += g;
-                s1 += g * sg.in[b * sg.width + ic];
+                s1 += g * in[b * sg.width];
             }
         }
-        acc[slice][j] = s0; acc2[slice][j] = s1;
+        acc[slice * kFreqCols + j] = s0; acc2[slice * kFreqCols + j] = s1;
         __syncthreads();
         if (slice == 0 && e < E && gm.off_w[si] >= 0) {
             double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-            for (int i = 0; i < kRedSlices; ++i) { t0 += acc[i][j]; t1 += acc2[i][j]; }
+            for (int i = 0; i < kFreqSlices; ++i) { t0 += acc[i * kFreqCols + j]; t1 += acc2[i * kFreqCols + j]; }
             grad[gm.off_b[si] + ee] = t0;
             grad[gm.off_w[si] + ee] = t1;
         }
     } else {
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-        for (long b = threadIdx.x; b < B; b += 64 * kRedSlices) {
+        for (long b = threadIdx.x; b < B; b += kRedThreads) {
             const double r = pred[b] - y[b];
             s0 += r * r; s1 += r; s2 += y[b] * y[b];
         }
-        __shared__ double red[3][64 * kRedSlices];
-        red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+        __shared__ double red3[kRedThreads];
+        acc[threadIdx.x] = s0; acc2[threadIdx.x] = s1; red3[threadIdx.x] = s2;
         __syncthreads();
-        for (int stride = 32 * kRedSlices; stride > 0; stride >>= 1) {
+        for (int stride = kRedThreads / 2; stride > 0; stride >>= 1) {
             if ((int)threadIdx.x < stride) {
-                red[0][threadIdx.x] += red[0][threadIdx.x + stride];
-                red[1][threadIdx.x] += red[1][threadIdx.x + stride];
-                red[2][threadIdx.x] += red[2][threadIdx.x + stride];
+                acc[threadIdx.x] += acc[threadIdx.x + stride];
+                acc2[threadIdx.x] += acc2[threadIdx.x + stride];
+                red3[threadIdx.x] += red3[threadIdx.x + stride];
             }
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            grad[gm.off_sse] = red[0][0];
-            grad[gm.off_sse + 1] = red[2][0];
-            if (gm.off_bias >= 0) grad[gm.off_bias] = 2.0 * inv_bt * red[1][0];
+            grad[gm.off_sse] = acc[0];
+            grad[gm.off_sse + 1] = red3[0];
+            if (gm.off_bias >= 0) grad[gm.off_bias] = 2.0 * inv_bt * acc2[0];
         }
     }
 }
@@ -489,7 +489,7 @@ const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, gates, gates_
     if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
     if (sh.blk > 0) {
         const long ncols = sh.blk * padded_3n(n_qubits);
-        hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(64 * kRedSlices), 0, st,
+        hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((ncols + red_cols(padded_3n(n_qubits)) - 1) / red_cols(padded_3n(n_qubits)))), dim3(kRedThreads), 0, st,
                            n_qubits, (int)sh.blk, padded_3n(n_qubits), L.nwaves, partial, w, grad_w);
     }
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
@@ -574,9 +574,9 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const doubl
     gm.off_ans = mi.off_ans; gm.off_bias = mi.off_bias; gm.off_sse = mi.P;
     for (int s = 0; s < 2; ++s) { gm.off_w[s] = mi.off_w[s]; gm.off_b[s] = mi.off_b[s]; }
     const int kw = padded_3n(mi.n);
-    const int nb_w = (int)((mi.sh.blk * kw + 63) / 64);
-    const int nb_x = mi.trainable ? (int)((mi.sh.E + 63) / 64) : 0;
-    hipLaunchKernelGGL(reduce_model_kernel, dim3((unsigned)(nb_w + nb_x + 1)), dim3(64 * kRedSlices), 0, st, mi.n,
+    const int nb_w = (int)((mi.sh.blk * kw + red_cols(kw) - 1) / red_cols(kw));
+    const int nb_x = mi.trainable ? (int)((mi.sh.E + kFreqCols - 1) / kFreqCols) : 0;
+    hipLaunchKernelGGL(reduce_model_kernel, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
                        (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
                        gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad);
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;

@@ -55,3 +55,48 @@ def golden_vectors():
                        x=V[nm + '.x'], w=V[nm + '.w'], g=V[nm + '.g'], out=V[nm + '.out'],
                        grad_x=V[nm + '.grad_x'], grad_w=V[nm + '.grad_w'])
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# Test double for CPU-only host-logic tests: an nn.Module with the HEACircuitHIP surface whose
+# arithmetic is the ORACLE.  Test infrastructure only -- the product never constructs it.
+# --------------------------------------------------------------------------------------------------
+def make_oracle_layer(n_wires, block_configs, ham_offset, ham_coeff):
+    import torch
+    import torch.nn as nn
+    from oracle import c_oracle as C
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            out = C.hea_forward(n_wires, block_configs, x.detach().numpy(), w.detach().numpy(), ham_offset, ham_coeff)
+            return torch.from_numpy(out)
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            _, gx, gw = C.hea_backward(n_wires, block_configs, x.detach().numpy(), w.detach().numpy(),
+                                       g.detach().numpy(), ham_offset, ham_coeff)
+            return torch.from_numpy(gx), torch.from_numpy(gw)
+
+    class OracleLayer(nn.Module):
+        def __init__(self, init):
+            super().__init__()
+            self.ansatz_weights = nn.Parameter(init.clone())
+
+        def forward(self, x):
+            return _Fn.apply(x, self.ansatz_weights).unsqueeze(-1)
+
+    return OracleLayer
+
+
+def quanonet_with_oracle_layer(n, b_in, t_in, net, seed=0):
+    """QuanONetPT (product class, host logic under test) with its quantum layer swapped for the oracle double."""
+    import torch
+    from quanonet_amd.models import QuanONetPT
+    torch.manual_seed(seed)
+    m = QuanONetPT(n, b_in, t_in, net, scale_coeff=0.1, if_trainable_freq=True)
+    q = m.quantum_layer
+    m.quantum_layer = make_oracle_layer(n, q.block_configs, q.ham_offset, q.ham_coeff)(q.ansatz_weights.data)
+    return m

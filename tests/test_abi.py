@@ -1,0 +1,127 @@
+"""
+CPU-side checks of the C-ABI shared library: it loads, exports every symbol that include/*.h declares,
+and its host-side argument validation behaves (no kernel is launched, no GPU needed).
+"""
+import ctypes
+import glob
+import os
+import re
+import subprocess
+
+import pytest
+
+from tests.conftest import ROOT
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from quanonet_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):            # normally built by __graft_entry__.build()
+        subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'quanonet_amd', 'csrc'), '-j', '8'])
+    return _lib.load()
+
+
+def declared_functions():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, 'include', '*.h')):
+        src = open(h).read()
+        src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+        for m in re.finditer(r'\b(qhea_[a-z0-9_]+)\s*\(', src):
+            names.add(m.group(1))
+    return sorted(names)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from quanonet_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 10
+    for n in names:
+        assert getattr(lib, n) is not None, n
+    assert set(_lib.EXPORTS) == set(names)
+
+
+def test_version_and_strerror(lib):
+    assert lib.qhea_version() >= 100
+    assert lib.qhea_strerror(0) == b'ok'
+    assert b'invalid' in lib.qhea_strerror(-1)
+    assert b'workspace' in lib.qhea_strerror(-3)
+
+
+def test_shape_validation_without_gpu(lib):
+    i32 = ctypes.c_int32
+    enc = (i32 * 3)(5, 5, 5)
+    ld = (i32 * 3)(2, 2, 1)
+    assert lib.qhea_workspace_bytes(5, 3, enc, ld, 1024) > 1024 * 15 * 16
+    assert lib.qhea_workspace_bytes(1, 3, enc, ld, 1024) == 0          # n < 2 rejected
+    assert lib.qhea_workspace_bytes(13, 3, enc, ld, 1024) == 0
+    bad = (i32 * 3)(5, -1, 5)
+    assert lib.qhea_workspace_bytes(5, 3, bad, ld, 8) == 0
+    # argument errors are reported before anything touches a device
+    assert lib.qhea_forward(1, 3, enc, ld, 4, None, None, 0.0, 1.0, None, None, None, None, 0, None) == -1
+    assert lib.qhea_forward(5, 3, enc, ld, 4, None, None, 0.0, 1.0, None, None, None, None, 0, None) == -1
+    assert lib.qhea_backward(5, 3, enc, ld, -1, None, None, 0.0, 1.0, None, None, None, None, None, None,
+                             None, 0, None) == -1
+    assert lib.qhea_forward(5, 3, enc, ld, 0, None, None, 0.0, 1.0, None, None, None, None, 0, None) == 0   # empty batch
+    # more than 16 distinct (enc, ld) runs is outside this build's kernel-argument budget
+    many_e = (i32 * 40)(*[5] * 40)
+    many_l = (i32 * 40)(*[(i % 2) + 1 for i in range(40)])
+    assert lib.qhea_workspace_bytes(5, 40, many_e, many_l, 8) == 0
+
+
+def test_model_descriptor(lib):
+    from quanonet_amd import _lib
+    d = _lib.make_model_desc(_lib.MODEL_QUANONET, 5, (40, 2, 20, 2), 100, 2, True, 0.1, 0.0, 1.0)
+    assert _lib.model_param_count(d) == 2401                     # SURVEY.md section 8 table, cfg 2
+    d2 = _lib.make_model_desc(_lib.MODEL_QUANONET, 2, (5, 1, 5, 1), 10, 1, True, 0.001, 0.0, 2.5)
+    assert _lib.model_param_count(d2) == 101                     # cfg 1
+    d3 = _lib.make_model_desc(_lib.MODEL_HEAQNN, 8, (20, 2), 102, 0, True, 0.1, 0.0, 0.625)
+    assert _lib.model_param_count(d3) == 1280                    # cfg 4
+    d4 = _lib.make_model_desc(_lib.MODEL_QUANONET, 12, (40, 2, 20, 2), 100, 2, True, 0.1, 0.0, 1.0)
+    assert _lib.model_param_count(d4) == 5761                    # cfg 5
+    ff = _lib.make_model_desc(_lib.MODEL_QUANONET, 5, (40, 2, 40, 2), 100, 2, False, 0.1, 0.0, 1.0)
+    assert _lib.model_param_count(ff) == 160 * 15 + 1
+    assert lib.qhea_model_workspace_bytes(ctypes.byref(d), 1024) > 0
+    bad = _lib.make_model_desc(7, 5, (1, 1, 1, 1), 3, 1, True, 0.1, 0.0, 1.0)
+    with pytest.raises(_lib.QheaError):
+        _lib.model_param_count(bad)
+
+
+def test_device_count_matches_torch(lib):
+    import torch
+    assert lib.qhea_device_count() == (torch.cuda.device_count() if torch.cuda.is_available() else 0)
+
+
+def test_module_surface_matches_reference_contract(lib):
+    """parameter name/shape/init, state_dict keys, errors."""
+    import numpy as np
+    import torch
+    from quanonet_amd.models import QuanONetPT, HEAQNNPT, _build_quantum_layer
+    from quanonet_amd.circuit import HEACircuitHIP, _make_block_configs, _ham_params
+    torch.manual_seed(0)
+    m = QuanONetPT(5, 100, 2, (40, 2, 20, 2), scale_coeff=0.1, if_trainable_freq=True)
+    sd = m.state_dict()
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == [
+        ('bias', (1,)), ('branch_freq.weights', (200,)), ('branch_freq.bias', (200,)),
+        ('trunk_freq.weights', (100,)), ('trunk_freq.bias', (100,)),
+        ('quantum_layer.ansatz_weights', (120, 3, 5))]
+    # the first torch RNG draw after manual_seed is the ansatz init, float32 U(-pi, pi) (quantum_circuits_tq.py:50-53)
+    torch.manual_seed(0)
+    ref = torch.empty(120, 3, 5).uniform_(-np.pi, np.pi)
+    assert torch.equal(sd['quantum_layer.ansatz_weights'].float(), ref)
+    assert float(sd['branch_freq.weights'][0]) == 0.1 and float(sd['trunk_freq.bias'].abs().sum()) == 0.0
+    h = HEAQNNPT(8, 102, (20, 2), scale_coeff=0.1, if_trainable_freq=True)
+    assert [k for k in h.state_dict()] == ['freq.weights', 'freq.bias', 'quantum_layer.ansatz_weights']
+    assert tuple(h.state_dict()['quantum_layer.ansatz_weights'].shape) == (40, 3, 8)
+    ff = QuanONetPT(5, 100, 2, (40, 2, 40, 2), scale_coeff=0.1, if_trainable_freq=False, ham_diag=np.arange(32.0))
+    assert list(ff.state_dict()) == ['bias', 'quantum_layer.ansatz_weights', 'quantum_layer.ham_diag']
+    assert _make_block_configs(5, 20, 2, 40, 2) == [(5, 2)] * 60
+    assert _ham_params(5, -5.0, 5.0) == (0.0, 1.0)
+    with pytest.raises(ValueError):
+        _build_quantum_layer('qiskit', 5, 300, (40, 2, 20, 2), (-5, 5), None, 100, 2)
+    with pytest.raises(ValueError):
+        HEACircuitHIP(1, [(1, 1)])
+    with pytest.raises(ValueError):
+        m.quantum_layer(torch.zeros(4, 7, dtype=torch.float64))
+    from quanonet_amd import _lib
+    with pytest.raises(_lib.QheaError):                            # no CPU fallback
+        m(torch.zeros(4, 100, dtype=torch.float64), torch.zeros(4, 2, dtype=torch.float64))

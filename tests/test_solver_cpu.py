@@ -1,0 +1,141 @@
+"""
+Host-side training logic on CPU: shard arithmetic, the flat-buffer data-parallel step over gloo
+(world_size 2) against the single-process full-batch step, checkpoint interop.  The circuit
+arithmetic in these tests is the oracle test double (tests/helpers.py); no GPU is touched.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests import helpers as H
+from quanonet_amd.solver import DataParallelTrainer, shard_slice
+
+
+def test_shard_slice_partitions_every_batch():
+    for n in (0, 1, 7, 100, 1023):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_slice(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+N, NET, B_IN, T_IN, GB, STEPS = 3, (2, 1, 2, 2), 6, 2, 23, 3     # odd global batch -> uneven shards
+
+
+def _data():
+    rng = np.random.default_rng(5)
+    return (torch.tensor(rng.normal(size=(STEPS, GB, B_IN))), torch.tensor(rng.uniform(size=(STEPS, GB, T_IN))),
+            torch.tensor(rng.normal(size=(STEPS, GB, 1))))
+
+
+def _single_process():
+    model = H.quanonet_with_oracle_layer(N, B_IN, T_IN, NET)
+    tr = DataParallelTrainer(model, lr=1e-2, fused=False)
+    br, tk, y = _data()
+    grads = []
+    for s in range(STEPS):
+        tr.train_step(br[s], tk[s], y[s], global_batch=GB)
+        grads.append(tr.flat.clone())
+    return tr.pflat.clone(), grads
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = H.quanonet_with_oracle_layer(N, B_IN, T_IN, NET, seed=rank)      # different init per rank on purpose
+    tr = DataParallelTrainer(model, lr=1e-2, world_size=world, dist=dist, fused=False)   # broadcasts rank 0's
+    br, tk, y = _data()
+    grads = []
+    for s in range(STEPS):
+        lo, hi = shard_slice(GB, rank, world)
+        tr.train_step(br[s, lo:hi], tk[s, lo:hi], y[s, lo:hi], global_batch=GB)
+        grads.append(tr.flat.clone().numpy())
+    q.put((rank, tr.pflat.clone().numpy(), grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_step_equals_single_process():
+    ref_params, ref_grads = _single_process()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0, g0), (_, p1, g1) = res
+    np.testing.assert_array_equal(p0, p1)                         # replicas stay bit-identical
+    for s in range(STEPS):
+        np.testing.assert_array_equal(g0[s], g1[s])               # all-reduced buffer identical on both ranks
+        np.testing.assert_allclose(g0[s], ref_grads[s].numpy(), rtol=0, atol=1e-12)   # == full-batch gradient (+sse, sum y^2)
+    np.testing.assert_allclose(p0, ref_params.numpy(), rtol=0, atol=1e-12)
+
+
+def test_flat_views_and_state_dict_order():
+    model = H.quanonet_with_oracle_layer(N, B_IN, T_IN, NET)
+    tr = DataParallelTrainer(model, lr=1e-2, fused=False)
+    names = [k for k, _ in model.named_parameters()]
+    assert names[0] == 'bias' and names[-1] == 'quantum_layer.ansatz_weights'
+    off = 0
+    for k, p in model.named_parameters():
+        assert p.data.data_ptr() == tr.pflat[off:].data_ptr()      # parameters alias the flat vector
+        assert p.grad.data_ptr() == tr.flat[off:].data_ptr()
+        off += p.numel()
+    assert off == tr.numel
+
+
+def test_checkpoint_roundtrip_and_name_parsing(tmp_path):
+    from quanonet_amd import checkpoint as ck
+    st = dict(np.load(os.path.join(H.GOLDEN, 'advection_q5.npz')))
+    pt = ck.ms_to_pt_state(st, 5, (40, 2, 20, 2))
+    assert pt['quantum_layer.ansatz_weights'].shape == (120, 3, 5)
+    np.testing.assert_array_equal(pt['quantum_layer.ansatz_weights'].reshape(-1), st['QuanONet.weight'].astype(np.float64))
+    back = ck.pt_to_ms_state(pt)
+    for k in st:
+        np.testing.assert_array_equal(np.asarray(back[k]).reshape(-1), st[k].astype(np.float64).reshape(-1))
+    cfg = ck.parse_experiment_dir('x/Advection_QuanONet_Net40-2-20-2_Q5_TF_S0.1_1000x100_Seed0/best_model.ckpt')
+    assert cfg == {'model_type': 'QuanONet', 'net_size': [40, 2, 20, 2], 'num_qubits': 5, 'scale_coeff': 0.1,
+                   'if_trainable_freq': True}
+    cfg2 = ck.parse_experiment_dir('RDiffusion_HEAQNN_Net64-2_Q8_FF_S0.01_TQ_1000x100_Seed3')
+    assert cfg2['model_type'] == 'HEAQNN' and cfg2['net_size'] == [64, 2] and cfg2['if_trainable_freq'] is False
+    # MindSpore .ckpt reader against a protobuf written here (same wire layout as SURVEY.md 8c)
+    def varint(v):
+        out = b''
+        while True:
+            b = v & 0x7F
+            v >>= 7
+            out += bytes([b | (0x80 if v else 0)])
+            if not v:
+                return out
+    def field(no, payload):
+        return varint((no << 3) | 2) + varint(len(payload)) + payload
+    arr = np.arange(6, dtype='<f4')
+    tensor = varint((1 << 3) | 0) + varint(2) + varint((1 << 3) | 0) + varint(3) + field(2, b'Float32') + field(3, arr.tobytes())
+    value = field(1, b'QuanONet.weight') + field(2, tensor)
+    path = tmp_path / 'm.ckpt'
+    path.write_bytes(field(1, value))
+    got = ck.read_mindspore_ckpt(str(path))
+    np.testing.assert_array_equal(got['QuanONet.weight'], arr.reshape(2, 3))
+    np.savez(tmp_path / 'w.npz', **st)
+    assert set(ck.load_weight_file(str(tmp_path / 'w.npz'))) == set(st)
