@@ -64,6 +64,15 @@ const char* qhea_strerror(int code);
 int qhea_device_count(void);
 
 /*
+ * Measurement hook (no reference counterpart): the NEXT qhea_backward / qhea_model_loss_grad /
+ * qhea_forward / qhea_model_forward call on this thread records `start_event` immediately before and
+ * `stop_event` immediately after its circuit kernel (fwd_kernel / bwd_kernel) on the call's stream, then
+ * the hook disarms itself.  Both are hipEvent_t handles created with timing enabled; pass NULLs to
+ * disarm.  Used by bench.py to time the dominant kernel alone with HIP events.
+ */
+int qhea_profile_next_circuit_kernel(void* start_event, void* stop_event);
+
+/*
  * Bytes of DEVICE scratch the calls below need for this circuit shape and batch.
  * Replaces: nothing in the reference (TorchQuantum allocates per-gate temporaries and
  * autograd saves every intermediate state; core/quantum_circuits_tq.py:74).

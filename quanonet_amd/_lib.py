@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libquanonet_hea.so')
 
 EXPORTS = ['qhea_version', 'qhea_strerror', 'qhea_device_count', 'qhea_workspace_bytes',
            'qhea_forward', 'qhea_backward', 'qhea_model_param_count', 'qhea_model_workspace_bytes',
-           'qhea_model_forward', 'qhea_model_loss_grad']
+           'qhea_model_forward', 'qhea_model_loss_grad', 'qhea_profile_next_circuit_kernel']
 
 
 class ModelDesc(ctypes.Structure):
@@ -59,6 +59,8 @@ def load():
     lib.qhea_backward.argtypes = [ctypes.c_int, ctypes.c_int, i32p, i32p, ctypes.c_int64, dp, dp,
                                   ctypes.c_double, ctypes.c_double, dp, dp, dp, dp, dp, dp,
                                   vp, ctypes.c_size_t, vp]
+    lib.qhea_profile_next_circuit_kernel.restype = ctypes.c_int
+    lib.qhea_profile_next_circuit_kernel.argtypes = [vp, vp]
     mdp = ctypes.POINTER(ModelDesc)
     lib.qhea_model_param_count.restype = ctypes.c_int64
     lib.qhea_model_param_count.argtypes = [mdp]
@@ -229,3 +231,10 @@ def model_loss_grad(desc, branch, trunk, y, params, inv_batch_total, grad, ham_d
                                       _ptr(ws), ws.numel(), _stream(branch.device))
     _check(rc, 'qhea_model_loss_grad')
     return grad
+
+
+def profile_next_circuit_kernel(start_event, stop_event):
+    """Arm the measurement hook with two torch.cuda.Event(enable_timing=True) (already recorded once)."""
+    rc = load().qhea_profile_next_circuit_kernel(ctypes.c_void_p(start_event.cuda_event),
+                                                 ctypes.c_void_p(stop_event.cuda_event))
+    _check(rc, 'qhea_profile_next_circuit_kernel')

@@ -153,6 +153,13 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     return L;
 }
 
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+inline void profile_begin(hipStream_t st) { if (g_ev_start) (void)hipEventRecord(g_ev_start, st); }
+inline void profile_end(hipStream_t st) {
+    if (g_ev_stop) (void)hipEventRecord(g_ev_stop, st);
+    g_ev_start = nullptr; g_ev_stop = nullptr;
+}
+
 int launch_prep(int n, const Shape& sh, int64_t B, const double* w, const double* x, char* ws, const Layout& L,
                 hipStream_t st) {
     const long total = (sh.blk + 2) * n + B * sh.E;
@@ -409,6 +416,12 @@ const char* qhea_strerror(int code) {
     }
 }
 
+int qhea_profile_next_circuit_kernel(void* start_event, void* stop_event) {
+    g_ev_start = static_cast<hipEvent_t>(start_event);
+    g_ev_stop = static_cast<hipEvent_t>(stop_event);
+    return QHEA_OK;
+}
+
 int qhea_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -443,12 +456,14 @@ int qhea_forward(int n_qubits, int n_blocks, const int32_t* enc_per_block, const
     const char* gates = ws + L.off_U;
     const int gates_bytes = (int)((sh.blk + 2) * n_qubits * kGateBytes);
 const FwdArgs fa{sh.runs, (long)batch, (int)sh.E, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, out, state_out, nullptr};
+    profile_begin(st);
     switch (n_qubits) {
 #define QHEA_CASE(NN) case NN: launch_fwd_##NN(grid, st, fa); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
         default: return QHEA_EUNSUPPORTED;
     }
+    profile_end(st);
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 
@@ -480,12 +495,14 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
     double* partial = reinterpret_cast<double*>(ws + L.off_part);
 const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, g,
                      state_in, nullptr, nullptr, 0.0, out, grad_x, partial};
+    profile_begin(st);
     switch (n_qubits) {
 #define QHEA_CASE(NN) case NN: launch_bwd_##NN(grid, st, ba); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
         default: return QHEA_EUNSUPPORTED;
     }
+    profile_end(st);
     if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
     if (sh.blk > 0) {
         const long ncols = sh.blk * padded_3n(n_qubits);
@@ -527,12 +544,14 @@ int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double*
     const FwdArgs fa{mi.sh.runs, (long)batch, (int)mi.sh.E, reinterpret_cast<const double2*>(ws + M.L.off_cs),
                      ws + M.L.off_U, (int)((mi.sh.blk + 2) * mi.n * kGateBytes), desc->ham_offset, desc->ham_coeff,
                      ham_diag, pred, nullptr, mi.has_bias ? params + mi.off_bias : nullptr};
+    profile_begin(st);
     switch (mi.n) {
 #define QHEA_CASE(NN) case NN: launch_fwd_##NN(grid, st, fa); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
         default: return QHEA_EUNSUPPORTED;
     }
+    profile_end(st);
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 
@@ -563,12 +582,14 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const doubl
                      (int)((mi.sh.blk + 2) * mi.n * kGateBytes), desc->ham_offset, desc->ham_coeff, ham_diag,
                      nullptr, nullptr, y, mi.has_bias ? params + mi.off_bias : nullptr, inv_batch_total,
                      pr, gx, partial};
+    profile_begin(st);
     switch (mi.n) {
 #define QHEA_CASE(NN) case NN: launch_bwd_##NN(grid, st, ba); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
         default: return QHEA_EUNSUPPORTED;
     }
+    profile_end(st);
     if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
     GradMap gm{};
     gm.off_ans = mi.off_ans; gm.off_bias = mi.off_bias; gm.off_sse = mi.P;

@@ -32,7 +32,9 @@ namespace qhea {
 
 constexpr int kWaves = 4;              // waves per workgroup
 constexpr int kMaxRuns = 16;           // run-length-encoded (count, enc, ld) block list
-constexpr int kCsPerWave = 1024;       // wave-private LDS staging of (cos,sin) pairs: 16 KB per wave
+constexpr int kCsPerWave = 512;        // wave-private LDS staging of (cos,sin) pairs: 8 KB per wave
+constexpr int kRedStride = 66;         // doubles per row of the wave-private reduction scratch (64 lanes + pad)
+constexpr int kRedPerWave = 16 * kRedStride;
 constexpr int kGateBytes = 64;         // one gate-table entry: 2 lane variants x (ar, s*ai, s*br, bi)
 
 struct Runs {
@@ -53,6 +55,8 @@ struct Cfg {
     static constexpr int KX = (N <= 2) ? 2 : (N <= 4) ? 4 : (N <= 8) ? 8 : 16;                   // padded N
     static constexpr int CAP = kCsPerWave / SPW;    // staged encoding columns per sample
     static constexpr int UD = (N <= 6) ? N : 1;     // gate-coefficient prefetch distance (gates)
+    static constexpr bool LDSRED = N <= 5;          // gradient sums through LDS (few instructions) instead of the
+                                                    // register butterfly (whose cost only amortises for long gates)
 };
 
 __host__ __device__ constexpr int padded_3n(int n) {
@@ -131,6 +135,65 @@ __device__ __forceinline__ void lane_reduce(double (&v)[K], int lane) {
         }
         lane_reduce<K, BITS, T + 1>(v, lane);
     }
+}
+
+// Sums through a wave-private LDS scratch (rows of kRedStride doubles, one row per value, one column
+// per lane).  Far fewer vector-ALU instructions than the register butterfly: K stores, K/2 wide loads,
+// K adds and log2(64/K) exchange-adds.  The wave reads only what it wrote itself (LDS is in-order per
+// wave), so no barrier is needed.  Summation order is fixed -> bitwise reproducible.
+//
+// The sums are split in two halves so that the LDS round trip overlaps the next sub-layer's gates:
+// *_put() stores the lane values and issues the loads (no wait), *_finish() adds them up one
+// sub-layer (or block) later.
+//
+// wave_sum: every lane contributes v[0..K); lane l ends with the 64-lane total of value l / (64/K).
+template <int K>
+__device__ __forceinline__ void wave_sum_put(const double (&v)[K], double* red, int lane, double (&t)[K]) {
+    static_assert(K == 8 || K == 16, "K");
+    constexpr int LPV = 64 / K;                       // lanes sharing one value
+#pragma unroll
+    for (int j = 0; j < K; ++j) red[j * kRedStride + lane] = v[j];
+    const double* row = red + (lane / LPV) * kRedStride + (lane % LPV) * K;
+#pragma unroll
+    for (int i = 0; i < K; ++i) t[i] = row[i];
+}
+template <int K>
+__device__ __forceinline__ double tree_sum(double (&t)[K]) {
+#pragma unroll
+    for (int w = K / 2; w > 0; w >>= 1)
+#pragma unroll
+        for (int i = 0; i < w; ++i) t[i] += t[i + w];
+    return t[0];
+}
+template <int K>
+__device__ __forceinline__ double wave_sum_finish(double (&t)[K]) {
+    double s = tree_sum<K>(t);
+    s += xchg<1>(s);
+    s += xchg<2>(s);
+    if constexpr (64 / K == 8) s += xchg<4>(s);
+    return s;
+}
+// sample_sum: every lane contributes v[0..K); a wave holds 64>>LB samples of 2^LB lanes.  Lane l ends
+// with the per-sample total of value (l / LPP) % K for sample (l / LPP) / K, LPP = 2^LB / K.
+template <int K, int LB>
+__device__ __forceinline__ void sample_sum_put(const double (&v)[K], double* red, int lane, double (&t)[K]) {
+    constexpr int LANES = 1 << LB;
+    constexpr int LPP = LANES / K;                    // lanes sharing one (sample, value) pair; each sums K entries
+    static_assert(LPP >= 1 && LPP <= 4, "LPP");
+#pragma unroll
+    for (int j = 0; j < K; ++j) red[j * kRedStride + lane] = v[j];
+    const int pidx = lane / LPP;
+    const double* row = red + (pidx % K) * kRedStride + (pidx / K) * LANES + (lane % LPP) * K;
+#pragma unroll
+    for (int i = 0; i < K; ++i) t[i] = row[i];
+}
+template <int K, int LB>
+__device__ __forceinline__ double sample_sum_finish(double (&t)[K]) {
+    constexpr int LPP = (1 << LB) / K;
+    double s = tree_sum<K>(t);
+    if constexpr (LPP >= 2) s += xchg<1>(s);
+    if constexpr (LPP >= 4) s += xchg<2>(s);
+    return s;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -450,6 +513,62 @@ struct CsStream {
     }
 };
 
+// Deferred gradient sums of the backward kernel (N <= 5): values go through the wave's LDS scratch; the
+// additions and the store of sub-layer s / block b run one sub-layer / block later.
+template <int N>
+struct GradSums {
+    using C = Cfg<N>;
+    double tw[C::KW];       // loaded rows of the pending sub-layer (X,Y,Z sums)
+    double tx[C::KX];       // loaded rows of the pending RX chunk
+    int sub_w, col_x, m_x;  // what is pending (-1: nothing)
+    double* red;
+    int lane;
+    long wave, B;
+    int E;
+    double* __restrict__ part_w;
+    double* __restrict__ grad_x;
+
+    __device__ __forceinline__ void flush_w() {
+        if (sub_w >= 0) {
+            const double tot = wave_sum_finish<C::KW>(tw);
+            constexpr int LPV = 64 / C::KW;
+            if (lane % LPV == 0) part_w[(long)sub_w * C::KW + lane / LPV] = tot;
+            sub_w = -1;
+        }
+    }
+    __device__ __forceinline__ void flush_x() {
+        if (col_x >= 0) {
+            const double tot = sample_sum_finish<C::KX, C::LB>(tx);
+            constexpr int LPP = C::LANES / C::KX;
+            const int pidx = lane / LPP, j = pidx % C::KX;
+            const long bs = wave * C::SPW + pidx / C::KX;
+            if (lane % LPP == 0 && j < m_x && bs < B) grad_x[bs * E + col_x + j] = tot;
+            col_x = -1;
+        }
+    }
+    __device__ __forceinline__ void put_w(const double (&acc3)[C::KW], int sub) {
+        flush_w();
+        wave_sum_put<C::KW>(acc3, red, lane, tw);
+        sub_w = sub;
+    }
+    __device__ __forceinline__ void put_x(const double (&gx)[C::KX], int col, int m) {
+        flush_x();
+        sample_sum_put<C::KX, C::LB>(gx, red, lane, tx);
+        col_x = col; m_x = m;
+    }
+};
+
+// register-butterfly versions (N >= 6)
+template <int N>
+__device__ __forceinline__ void store_grad_x(double (&gx)[Cfg<N>::KX], int lane, long wave, long B,
+                                             int E, double* __restrict__ grad_x, int col, int m) {
+    using C = Cfg<N>;
+    lane_reduce<C::KX, C::LB>(gx, lane);          // lane with klow == j holds value j (KX <= 2^LB for every N)
+    const int klow = lane & (C::LANES - 1);
+    const long bs = wave * C::SPW + (lane >> C::LB);
+    if (bs < B && klow < m) grad_x[bs * E + col + klow] = gx[0];
+}
+
 // ---------------------------------------------------------------------------------------
 // forward sweep (shared by the forward and backward kernels)
 // ---------------------------------------------------------------------------------------
@@ -558,8 +677,10 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
                                                           double* __restrict__ partial) {
     using C = Cfg<N>;
     __shared__ double2 cs_lds[kWaves * kCsPerWave + 16];   // +16: slack for the unclamped prefetch
+    __shared__ double red_lds[C::LDSRED ? kWaves * kRedPerWave : 1];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
+    double* red = red_lds + (C::LDSRED ? wib * kRedPerWave : 0);
     const long wave = (long)blockIdx.x * kWaves + wib;
     const long b_raw = wave * C::SPW + (lane >> C::LB);
     const bool valid = b_raw < B;
@@ -608,6 +729,9 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
     }
 
     double* __restrict__ part_w = partial + wave * (long)blk * C::KW;
+    GradSums<N> sums;
+    sums.sub_w = -1; sums.col_x = -1; sums.m_x = 0; sums.red = red; sums.lane = lane; sums.wave = wave; sums.B = B;
+    sums.E = E; sums.part_w = part_w; sums.grad_x = grad_x;
     int col = E, sub = blk;
     gs.template prime<false>(blk - 1);
     for (int ri = runs.nruns - 1; ri >= 0; --ri) {
@@ -631,8 +755,12 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
                     gs.template done<false, Q>();
                 });
                 gs.template advance<false>();
-                lane_reduce<C::KW, 6>(acc3, lane);
-                if (lane < C::KW) part_w[(long)sub * C::KW + lane] = acc3[0];
+                if constexpr (C::LDSRED) {
+                    sums.put_w(acc3, sub);
+                } else {
+                    lane_reduce<C::KW, 6>(acc3, lane);
+                    if (lane < C::KW) part_w[(long)sub * C::KW + lane] = acc3[0];
+                }
             }
             col -= ne;
             if (one_chunk) {
@@ -649,9 +777,8 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
                             apply_rx<N, Q>(lr, li, csx.nxt[Q].x, -csx.nxt[Q].y);
                         }
                     });
-                    lane_reduce<C::KX, C::LB>(gx, lane);
-                    // lane with klow == j holds value j (KX <= 2^LB for every N)
-                    if (valid && klow < ne) grad_x[b * E + col + klow] = gx[0];
+                    if constexpr (C::LDSRED) sums.put_x(gx, col, ne);
+                    else store_grad_x<N>(gx, lane, wave, B, E, grad_x, col, ne);
                 }
             } else {
                 const int nchunks = (ne + N - 1) / N;
@@ -671,12 +798,13 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
                             apply_rx<N, Q>(lr, li, c.x, -c.y);
                         }
                     });
-                    lane_reduce<C::KX, C::LB>(gx, lane);
-                    if (valid && klow < m) grad_x[b * E + col + j0 + klow] = gx[0];
+                    if constexpr (C::LDSRED) sums.put_x(gx, col + j0, m);
+                    else store_grad_x<N>(gx, lane, wave, B, E, grad_x, col + j0, m);
                 }
             }
         }
     }
+    if constexpr (C::LDSRED) { sums.flush_w(); sums.flush_x(); }
 }
 
 // ---------------------------------------------------------------------------------------
