@@ -392,51 +392,73 @@ __device__ __forceinline__ double ham_weight(int k, double off, double co, const
 // per-sample RX (cos,sin) pairs (wave-private LDS window + one-block register prefetch)
 // ---------------------------------------------------------------------------------------
 // Gate table (built by prep_kernel): entry g = sub*N + q is 64 bytes = two double4 variants,
-// variant v for lanes whose bit q is v.  The table has N identity entries of padding on both
-// sides so that the prefetch may run past either end.  It is read with buffer loads: descriptor
-// and gate offset in SGPRs, the per-lane variant offset (0/32) in a VGPR -> no address arithmetic
-// on the vector ALU.  N <= 8: one register slot per qubit, refilled in place with the NEXT
-// sub-layer's coefficients right after use (a whole sub-layer of prefetch distance, no copies).
-// N >= 9: gates are long; the next gate's coefficients are fetched while the current one runs.
+// variant v for lanes whose bit q is v; one sub-layer = 64N contiguous bytes; N identity entries of
+// padding on both sides.  Every lane needs one 32-byte variant per gate, but a wave only ever needs 2N
+// distinct ones per sub-layer, and per-lane vector loads of them would cost the CU's single texture path
+// 2 KB per gate per wave (measured: 36 % of the forward kernel).  So each wave streams the table through
+// a private two-slot LDS ring instead: ONE buffer_load_dwordx4 (lanes 0..4N-1, 16 B each) fetches a whole
+// sub-layer two sub-layers ahead, ONE ds_write_b128 parks it, and the lanes pick their variant with
+// broadcast ds_read_b128 one sub-layer ahead (N <= 8: one register slot per qubit refilled in place right
+// after use; N >= 9: the next gate's coefficients are read while the current, long gate runs).
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kRingBytesPerWave = 2 * QHEA_MAX_QUBITS * kGateBytes;      // two sub-layers
 
 template <int N>
 struct GateStream {
     using C = Cfg<N>;
     static constexpr bool SLOTS = N <= 8;
+    static constexpr int SUBBYTES = N * kGateBytes;
     double4 slot[SLOTS ? N : 1];
+    u32x4 stage;                    // this lane's 16 B of the sub-layer in flight from global memory
     rsrc_t rsrc;
-    int soff;                       // wave-uniform byte offset of entry (sub, 0) from the table start
+    char* ring;                     // wave-private LDS: 2 x SUBBYTES
+    int sub;                        // current sub-layer (wave-uniform)
+    unsigned lane16;                // lane * 16 (clamped): byte offset of this lane's 16 B within a sub-layer
+    bool loader;                    // lane < 4N
     unsigned voff[N];               // per-lane variant offset (0 or 32) for each qubit
 
-    __device__ __forceinline__ void init(const char* table, int table_bytes, int lane) {
+    __device__ __forceinline__ void init(const char* table, int table_bytes, char* ring_wave, int lane) {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(table), 0, table_bytes, 0x00020000);
+        ring = ring_wave;
+        loader = lane < 4 * N;
+        lane16 = loader ? (unsigned)lane * 16u : 0u;
         static_for<0, N>([&](auto q) {
             constexpr int Q = decltype(q)::value;
             voff[Q] = (Q < C::LB) ? (((unsigned)lane >> Q) & 1u) * 32u : 0u;
         });
     }
-    template <int G>                 // G = gate offset relative to (sub, 0); may be negative or >= N
-    __device__ __forceinline__ double4 load() const {
-        constexpr int Q = ((G % N) + N) % N;
-        const int so = soff + G * kGateBytes;
-        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[Q], so, 0);
-        const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[Q], so + 16, 0);
-        double4 r;
-        r.x = __hiloint2double((int)lo.y, (int)lo.x); r.y = __hiloint2double((int)lo.w, (int)lo.z);
-        r.z = __hiloint2double((int)hi.y, (int)hi.x); r.w = __hiloint2double((int)hi.w, (int)hi.z);
-        return r;
+    __device__ __forceinline__ char* buf(int s) const { return ring + ((s & 1) ? SUBBYTES : 0); }
+    __device__ __forceinline__ u32x4 gload(int s) const {          // sub-layer s (-1 and blk are the padding)
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, (s + 1) * SUBBYTES, 0);
     }
-    // position at sub-layer `sub` for a forward (first gate (sub,0)) or reverse (first gate (sub,N-1)) walk
+    __device__ __forceinline__ void park(int s) {                   // stage -> LDS slot of sub-layer s
+        if (loader) *reinterpret_cast<u32x4*>(buf(s) + lane16) = stage;
+    }
+    template <int Q>
+    __device__ __forceinline__ double4 pick(int s) const {          // this lane's variant of gate (s, Q)
+        return *reinterpret_cast<const double4*>(buf(s) + Q * kGateBytes + voff[Q]);
+    }
+    // position at sub-layer s0 for a forward (dir +1) or reverse (dir -1) walk
     template <bool FWD>
-    __device__ __forceinline__ void prime(int sub) {
-        soff = (sub + 1) * N * kGateBytes;            // +1: front padding
+    __device__ __forceinline__ void prime(int s0) {
+        constexpr int D = FWD ? 1 : -1;
+        sub = s0;
+        stage = gload(s0);
+        park(s0);
+        stage = gload(s0 + D);
         if constexpr (SLOTS) {
-            static_for<0, N>([&](auto q) { slot[decltype(q)::value] = load<decltype(q)::value>(); });
+            static_for<0, N>([&](auto q) { slot[decltype(q)::value] = pick<decltype(q)::value>(s0); });
         } else {
-            slot[0] = FWD ? load<0>() : load<N - 1>();
+            slot[0] = FWD ? pick<0>(s0) : pick<N - 1>(s0);
         }
+    }
+    // top of a sub-layer: park the next sub-layer's table (fetched one sub-layer ago), fetch the one after
+    template <bool FWD>
+    __device__ __forceinline__ void begin() {
+        constexpr int D = FWD ? 1 : -1;
+        park(sub + D);
+        stage = gload(sub + 2 * D);
     }
     // use: u = gs.cur<FWD,Q>(); ...apply...; gs.done<FWD,Q>();
     template <bool FWD, int Q>
@@ -445,16 +467,17 @@ struct GateStream {
             return slot[Q];
         } else {
             const double4 u = slot[0];
-            slot[0] = FWD ? load<Q + 1>() : load<Q - 1>();
+            if constexpr (FWD) slot[0] = (Q + 1 < N) ? pick<(Q + 1) % N>(sub) : pick<0>(sub + 1);
+            else               slot[0] = (Q > 0) ? pick<(Q + N - 1) % N>(sub) : pick<N - 1>(sub - 1);
             return u;
         }
     }
     template <bool FWD, int Q>
     __device__ __forceinline__ void done() {
-        if constexpr (SLOTS) slot[Q] = FWD ? load<Q + N>() : load<Q - N>();
+        if constexpr (SLOTS) slot[Q] = pick<Q>(sub + (FWD ? 1 : -1));
     }
     template <bool FWD>
-    __device__ __forceinline__ void advance() { soff += (FWD ? N : -N) * kGateBytes; }
+    __device__ __forceinline__ void advance() { sub += FWD ? 1 : -1; }
 };
 
 template <int N>
@@ -599,8 +622,9 @@ __device__ __forceinline__ void forward_sweep(double (&re)[Cfg<N>::R], double (&
                 });
             }
             col += ne;
-            if (nld == 0) csx.template prefetch<true>(col);
+            csx.template prefetch<true>(col);              // next block's angles: two sub-layers of cover
             for (int l = 0; l < nld; ++l) {
+                gs.template begin<true>();
                 static_for<0, N>([&](auto q) {
                     constexpr int Q = decltype(q)::value;
                     const double4 u = gs.template cur<true, Q>();
@@ -608,7 +632,6 @@ __device__ __forceinline__ void forward_sweep(double (&re)[Cfg<N>::R], double (&
                     gs.template done<true, Q>();
                 });
                 gs.template advance<true>();
-                if (l == nld - 1) csx.template prefetch<true>(col);
                 apply_ring<N, false>(re, im, lane, ring_fwd);
             }
         }
@@ -629,6 +652,7 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_kernel(Runs runs, long B, int
                                                           const double* __restrict__ bias) {
     using C = Cfg<N>;
     __shared__ double2 cs_lds[kWaves * kCsPerWave + 16];   // +16: slack for the unclamped prefetch
+    __shared__ __attribute__((aligned(16))) char gate_ring[kWaves * kRingBytesPerWave];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const long wave = (long)blockIdx.x * kWaves + wib;
@@ -641,7 +665,7 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_kernel(Runs runs, long B, int
     CsStream<N> csx;
     csx.init(cs_lds + wib * kCsPerWave, cs, b, E, lane);
     GateStream<N> gs;
-    gs.init(gates, gates_bytes, lane);
+    gs.init(gates, gates_bytes, gate_ring + wib * kRingBytesPerWave, lane);
 
     double re[C::R], im[C::R];
     forward_sweep<N>(re, im, runs, csx, gs, lane, ring_fwd);
@@ -678,6 +702,7 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
     using C = Cfg<N>;
     __shared__ double2 cs_lds[kWaves * kCsPerWave + 16];   // +16: slack for the unclamped prefetch
     __shared__ double red_lds[C::LDSRED ? kWaves * kRedPerWave : 1];
+    __shared__ __attribute__((aligned(16))) char gate_ring[kWaves * kRingBytesPerWave];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     double* red = red_lds + (C::LDSRED ? wib * kRedPerWave : 0);
@@ -692,7 +717,7 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
     CsStream<N> csx;
     csx.init(cs_lds + wib * kCsPerWave, cs, b, E, lane);
     GateStream<N> gs;
-    gs.init(gates, gates_bytes, lane);
+    gs.init(gates, gates_bytes, gate_ring + wib * kRingBytesPerWave, lane);
 
     double pr[C::R], pi[C::R], lr[C::R], li[C::R];
     if (state_in) {
@@ -738,14 +763,15 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
         const int ne = runs.enc[ri], nld = runs.ld[ri];
         const bool one_chunk = ne <= N;
         for (int rep = 0; rep < runs.count[ri]; ++rep) {
+            if (one_chunk && ne > 0) csx.template prefetch<false>(col - ne);     // this block's angles, used after its sub-layers
             for (int l = nld - 1; l >= 0; --l) {
                 --sub;
-                if (l == 0 && one_chunk && ne > 0) csx.template prefetch<false>(col - ne);
                 apply_ring<N, true>(pr, pi, lane, ring_rev);
                 apply_ring<N, true>(lr, li, lane, ring_rev);
                 double acc3[C::KW];
 #pragma unroll
                 for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
+                gs.template begin<false>();
                 static_rfor<0, N>([&](auto q) {
                     constexpr int Q = decltype(q)::value;
                     const double4 u = gs.template cur<false, Q>();
@@ -765,7 +791,6 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
             col -= ne;
             if (one_chunk) {
                 if (ne > 0) {
-                    if (nld == 0) csx.template prefetch<false>(col);
                     double gx[C::KX];
 #pragma unroll
                     for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
