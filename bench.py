@@ -83,6 +83,8 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='collective backend; "gloo" + --same-device rehearses N>1 on one GPU')
+    ap.add_argument('--same-device', action='store_true', help='rehearsal only: every rank uses cuda:0')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -90,12 +92,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)          # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from quanonet_amd.models import QuanONetPT

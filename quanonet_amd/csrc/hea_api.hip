@@ -1,5 +1,7 @@
 // hea_api.hip -- C ABI (include/quanonet_hea.h) of the MI355X HEA simulator: argument checks,
 // workspace layout, the batch-invariant prep / reduce kernels and the per-qubit-count dispatch.
+#include <cstdlib>
+
 #include "hea_device.hpp"
 
 namespace qhea {
@@ -136,15 +138,42 @@ inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
     size_t off_U, off_cs, off_part, total;
-    long nwaves;
+    long nwaves, nwaves_fwd;
+    bool dup;
 };
+
+// psi/lambda-split backward kernel (n <= 5): chosen when even at half the samples per wave the batch does not
+// give every SIMD a wave, i.e. the packed kernel would leave SIMDs idle (hea_device.hpp: bwd_dup_kernel)
+int simd_count() {
+    static int cached = 0;
+    if (cached == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            cached = 4 * cus;
+        else
+            return 1024;                               // MI355X: 256 CUs x 4 SIMDs (used when no device is visible)
+    }
+    return cached;
+}
+bool use_dup(int n, int64_t B) {
+    if (n > 5 || B <= 0) return false;
+    if (const char* e = getenv("QHEA_BACKWARD_KERNEL")) {     // test hook: "packed" / "split" force a variant
+        if (e[0] == 'p') return false;
+        if (e[0] == 's') return true;
+    }
+    const int spwd = 32 >> n;
+    return (B + spwd - 1) / spwd <= simd_count();
+}
 
 Layout make_layout(int n, const Shape& sh, int64_t B) {
     Layout L{};
-    const int spw = n < 6 ? (64 >> n) : 1;
-    L.nwaves = (B + spw - 1) / spw;
-    const long nwg = (L.nwaves + kWaves - 1) / kWaves;
-    L.nwaves = nwg * kWaves;                       // padding waves write zeros
+    const int spw_packed = n < 6 ? (64 >> n) : 1;
+    L.dup = use_dup(n, B);
+    const int spw = L.dup ? (32 >> n) : spw_packed;
+    auto round_waves = [](long w) { return ((w + kWaves - 1) / kWaves) * kWaves; };   // padding waves write zeros
+    L.nwaves_fwd = round_waves((B + spw_packed - 1) / spw_packed);
+    L.nwaves = round_waves((B + spw - 1) / spw);                                      // backward-kernel waves
     size_t p = 0;
     L.off_U = p;    p = align_up(p + (size_t)(sh.blk + 2) * n * kGateBytes);
     L.off_cs = p;   p = align_up(p + (size_t)B * sh.E * sizeof(double2));
@@ -451,7 +480,7 @@ int qhea_forward(int n_qubits, int n_blocks, const int32_t* enc_per_block, const
     char* ws = static_cast<char*>(workspace);
     rc = launch_prep(n_qubits, sh, batch, w, x, ws, L, st);
     if (rc != QHEA_OK) return rc;
-    const dim3 grid((unsigned)(L.nwaves / kWaves));
+    const dim3 grid((unsigned)(L.nwaves_fwd / kWaves));
     const double2* cs = reinterpret_cast<const double2*>(ws + L.off_cs);
     const char* gates = ws + L.off_U;
     const int gates_bytes = (int)((sh.blk + 2) * n_qubits * kGateBytes);
@@ -497,7 +526,7 @@ const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, gates, gates_
                      state_in, nullptr, nullptr, 0.0, out, grad_x, partial};
     profile_begin(st);
     switch (n_qubits) {
-#define QHEA_CASE(NN) case NN: launch_bwd_##NN(grid, st, ba); break;
+#define QHEA_CASE(NN) case NN: if (L.dup) launch_bwd_dup_##NN(grid, st, ba); else launch_bwd_##NN(grid, st, ba); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
         default: return QHEA_EUNSUPPORTED;
@@ -540,7 +569,7 @@ int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double*
     const EncDesc enc = make_enc(desc, mi, branch, trunk, params);
     rc = launch_prep_model(mi, batch, params, enc, ws, M.L, st);
     if (rc != QHEA_OK) return rc;
-    const dim3 grid((unsigned)(M.L.nwaves / kWaves));
+    const dim3 grid((unsigned)(M.L.nwaves_fwd / kWaves));
     const FwdArgs fa{mi.sh.runs, (long)batch, (int)mi.sh.E, reinterpret_cast<const double2*>(ws + M.L.off_cs),
                      ws + M.L.off_U, (int)((mi.sh.blk + 2) * mi.n * kGateBytes), desc->ham_offset, desc->ham_coeff,
                      ham_diag, pred, nullptr, mi.has_bias ? params + mi.off_bias : nullptr};
@@ -584,7 +613,7 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const doubl
                      pr, gx, partial};
     profile_begin(st);
     switch (mi.n) {
-#define QHEA_CASE(NN) case NN: launch_bwd_##NN(grid, st, ba); break;
+#define QHEA_CASE(NN) case NN: if (M.L.dup) launch_bwd_dup_##NN(grid, st, ba); else launch_bwd_##NN(grid, st, ba); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
         default: return QHEA_EUNSUPPORTED;
