@@ -139,7 +139,7 @@ inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 struct Layout {
     size_t off_U, off_cs, off_part, total;
     long nwaves, nwaves_fwd;
-    bool dup;
+    bool dup, lds_fwd, lds_bwd;
 };
 
 // psi/lambda-split backward kernel (n <= 5): chosen when even at half the samples per wave the batch does not
@@ -166,14 +166,27 @@ bool use_dup(int n, int64_t B) {
     return (B + spwd - 1) / spwd <= simd_count();
 }
 
+// LDS-resident kernels (hea_lds.hip) where the wave-resident ones spill badly: n = 12 (measured, 12 sub-layers,
+// B = 1024: backward 2.5 ms vs 14.5 ms, forward 0.67 vs 0.79 ms; at n = 11 the wave-resident kernels still win)
+bool use_lds(int n, bool backward) {
+    if (const char* e = getenv("QHEA_LDS_KERNEL")) {           // test hook: "force" / "off"
+        if (e[0] == 'f') return true;
+        if (e[0] == 'o') return false;
+    }
+    (void)backward;
+    return n >= 12;
+}
+
 Layout make_layout(int n, const Shape& sh, int64_t B) {
     Layout L{};
     const int spw_packed = n < 6 ? (64 >> n) : 1;
-    L.dup = use_dup(n, B);
-    const int spw = L.dup ? (32 >> n) : spw_packed;
+    L.lds_fwd = use_lds(n, false);
+    L.lds_bwd = use_lds(n, true);
+    L.dup = !L.lds_bwd && use_dup(n, B);
+    const int spw = L.lds_bwd ? 1 : (L.dup ? (32 >> n) : spw_packed);
     auto round_waves = [](long w) { return ((w + kWaves - 1) / kWaves) * kWaves; };   // padding waves write zeros
     L.nwaves_fwd = round_waves((B + spw_packed - 1) / spw_packed);
-    L.nwaves = round_waves((B + spw - 1) / spw);                                      // backward-kernel waves
+    L.nwaves = L.lds_bwd ? B : round_waves((B + spw - 1) / spw);                      // backward partial rows
     size_t p = 0;
     L.off_U = p;    p = align_up(p + (size_t)(sh.blk + 2) * n * kGateBytes);
     L.off_cs = p;   p = align_up(p + (size_t)B * sh.E * sizeof(double2));
@@ -486,7 +499,9 @@ int qhea_forward(int n_qubits, int n_blocks, const int32_t* enc_per_block, const
     const int gates_bytes = (int)((sh.blk + 2) * n_qubits * kGateBytes);
 const FwdArgs fa{sh.runs, (long)batch, (int)sh.E, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, out, state_out, nullptr};
     profile_begin(st);
-    switch (n_qubits) {
+    if (L.lds_fwd) {
+        if (launch_lds_fwd(n_qubits, (long)batch, st, fa) != QHEA_OK) return QHEA_ELAUNCH;
+    } else switch (n_qubits) {
 #define QHEA_CASE(NN) case NN: launch_fwd_##NN(grid, st, fa); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
@@ -525,7 +540,9 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
 const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, g,
                      state_in, nullptr, nullptr, 0.0, out, grad_x, partial};
     profile_begin(st);
-    switch (n_qubits) {
+    if (L.lds_bwd) {
+        if (launch_lds_bwd(n_qubits, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;
+    } else switch (n_qubits) {
 #define QHEA_CASE(NN) case NN: if (L.dup) launch_bwd_dup_##NN(grid, st, ba); else launch_bwd_##NN(grid, st, ba); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
@@ -574,7 +591,9 @@ int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double*
                      ws + M.L.off_U, (int)((mi.sh.blk + 2) * mi.n * kGateBytes), desc->ham_offset, desc->ham_coeff,
                      ham_diag, pred, nullptr, mi.has_bias ? params + mi.off_bias : nullptr};
     profile_begin(st);
-    switch (mi.n) {
+    if (M.L.lds_fwd) {
+        if (launch_lds_fwd(mi.n, (long)batch, st, fa) != QHEA_OK) return QHEA_ELAUNCH;
+    } else switch (mi.n) {
 #define QHEA_CASE(NN) case NN: launch_fwd_##NN(grid, st, fa); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
@@ -612,7 +631,9 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const doubl
                      nullptr, nullptr, y, mi.has_bias ? params + mi.off_bias : nullptr, inv_batch_total,
                      pr, gx, partial};
     profile_begin(st);
-    switch (mi.n) {
+    if (M.L.lds_bwd) {
+        if (launch_lds_bwd(mi.n, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;
+    } else switch (mi.n) {
 #define QHEA_CASE(NN) case NN: if (M.L.dup) launch_bwd_dup_##NN(grid, st, ba); else launch_bwd_##NN(grid, st, ba); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE

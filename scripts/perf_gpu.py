@@ -50,3 +50,9 @@ if __name__ == '__main__':
         case(8, O.block_configs_heaqnn(8, (20, 2)), 2048)
     if 'cfg5' in which:
         case(12, O.block_configs_quanonet(12, (40, 2, 20, 2)), 1024, check=False, reps=5)
+    if 'bign' in which:
+        for n in (8, 9, 10, 11, 12):
+            case(n, O.block_configs_quanonet(n, (4, 2, 2, 2)), 1024, check=False, reps=5)
+    if 'ldsbig' in which:
+        for n in (10, 11, 12):
+            case(n, O.block_configs_quanonet(n, (4, 2, 2, 2)), 1024, check=False, reps=5)

@@ -77,6 +77,29 @@ def test_every_qubit_count_against_oracle(dev, n, backward_variant):
         np.testing.assert_allclose(gw, rgw, rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize('n', [2, 3, 5, 6, 8, 9, 11, 12])
+def test_lds_resident_kernels_against_oracle(dev, n, monkeypatch):
+    """hea_lds.hip (selected automatically for the largest n) forced on for every qubit count."""
+    monkeypatch.setenv('QHEA_LDS_KERNEL', 'force')
+    rng = np.random.default_rng(300 + n)
+    cfgs = [(n, 2), (n, 1)] if n > 8 else [(n, 2), (n, 1), (n + 3, 2), (n, 0)]
+    E, blk = O.circuit_sizes(n, cfgs)
+    B = 5 if n > 8 else 11
+    x = rng.uniform(-np.pi, np.pi, (B, E))
+    w = rng.uniform(-np.pi, np.pi, (blk, 3, n))
+    g = rng.normal(size=B)
+    off, co = O.ham_params(n, -3.0, 7.0)
+    ro, rst = C.hea_forward(n, cfgs, x, w, off, co, return_state=True)
+    _, rgx, rgw = C.hea_backward(n, cfgs, x, w, g, off, co)
+    for use_state in (True, False):
+        out, st, gx, gw, out2 = _run(n, cfgs, x, w, g, dev, off, co, use_state=use_state)
+        np.testing.assert_allclose(out, ro, rtol=0, atol=TOL)
+        np.testing.assert_allclose(out2, ro, rtol=0, atol=TOL)
+        np.testing.assert_allclose(st, rst, rtol=0, atol=TOL)
+        np.testing.assert_allclose(gx, rgx, rtol=0, atol=TOL)
+        np.testing.assert_allclose(gw, rgw, rtol=0, atol=TOL)
+
+
 def test_ham_diag_readout(dev):
     n, cfgs = 4, [(4, 1), (4, 2)]
     rng = np.random.default_rng(7)
