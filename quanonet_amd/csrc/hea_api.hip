@@ -356,8 +356,6 @@ int model_info(const qhea_model_desc* d, ModelInfo& mi) {
     mi.n = n;
     mi.trainable = d->trainable_freq != 0;
     long nb = 0;
-    int enc[1], ld[1];
-    (void)enc; (void)ld;
     // block list: QuanONet = td x (n, tl) then bd x (n, bl) (core/quantum_circuits_tq.py:130-138); HEAQNN = depth x (n, ld)
     int32_t* e = nullptr; int32_t* l = nullptr;
     long Eb = 0, Et = 0;
@@ -497,7 +495,8 @@ int qhea_forward(int n_qubits, int n_blocks, const int32_t* enc_per_block, const
     const double2* cs = reinterpret_cast<const double2*>(ws + L.off_cs);
     const char* gates = ws + L.off_U;
     const int gates_bytes = (int)((sh.blk + 2) * n_qubits * kGateBytes);
-const FwdArgs fa{sh.runs, (long)batch, (int)sh.E, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, out, state_out, nullptr};
+    const FwdArgs fa{sh.runs, (long)batch, (int)sh.E, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, out,
+                     state_out, nullptr};
     profile_begin(st);
     if (L.lds_fwd) {
         if (launch_lds_fwd(n_qubits, (long)batch, st, fa) != QHEA_OK) return QHEA_ELAUNCH;
@@ -537,7 +536,7 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
     const char* gates = ws + L.off_U;
     const int gates_bytes = (int)((sh.blk + 2) * n_qubits * kGateBytes);
     double* partial = reinterpret_cast<double*>(ws + L.off_part);
-const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, g,
+    const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, g,
                      state_in, nullptr, nullptr, 0.0, out, grad_x, partial};
     profile_begin(st);
     if (L.lds_bwd) {

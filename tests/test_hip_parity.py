@@ -255,3 +255,61 @@ def test_training_reduces_loss_and_steps_are_deterministic(dev):
         losses.append(hist)
     assert losses[0] == losses[1]                  # bitwise reproducible
     assert losses[0][-1] < 0.7 * losses[0][0]
+
+
+def test_ptsolver_end_to_end(dev, tmp_path):
+    """PTSolver (mirror of solvers/solver_pt.py): train, best/final checkpoints with the reference's keys, evaluate."""
+    from quanonet_amd.solver import PTSolver
+    rng = np.random.default_rng(0)
+    ntr, nte, b_in, t_in = 600, 200, 8, 1
+    def make(nrows):
+        br = rng.normal(size=(nrows, b_in)); tr = rng.uniform(size=(nrows, t_in))
+        y = (np.sin(2.0 * tr[:, 0]) * br[:, 0] * 0.5)[:, None]
+        return br, tr, y
+    br, tr, y = make(ntr); bre, tre, ye = make(nte)
+    data = {'train_branch_input': br, 'train_trunk_input': tr, 'train_output': y,
+            'test_branch_input': bre, 'test_trunk_input': tre, 'test_output': ye}
+    cfg = {'model_type': 'QuanONet', 'operator': 'Synthetic', 'num_qubits': 3, 'net_size': [3, 1, 2, 1],
+           'scale_coeff': 0.1, 'if_trainable_freq': 'true', 'learning_rate': 2e-2, 'batch_size': 100,
+           'num_epochs': 12, 'prefix': str(tmp_path), 'run_id': 'run0'}
+    np.random.seed(0); torch.manual_seed(0)
+    s = PTSolver(cfg, data, device=dev, log=lambda *a, **k: None)
+    hist = s.train()
+    assert len(hist['loss_train']) == 12 and hist['loss_train'][-1] < 0.8 * hist['loss_train'][0]
+    m = s.evaluate(hist)
+    assert set(m) == {'MSE', 'MAE', 'Max_Error', 'rel_l2'} and np.isfinite(m['rel_l2'])
+    out_dir = s.out_dir
+    import os, json
+    for f in ('best_model.pt', 'best_model.npz', 'final_model.pt', 'final_model.npz', 'metric.json'):
+        assert os.path.exists(os.path.join(out_dir, f)), f
+    z = np.load(os.path.join(out_dir, 'best_model.npz'))
+    assert sorted(z.files) == sorted(['bias', 'branch_freq.weights', 'branch_freq.bias', 'trunk_freq.weights',
+                                      'trunk_freq.bias', 'quantum_layer.ansatz_weights'])
+    # the evaluation path (qhea_model_forward) equals the oracle on the saved best weights
+    params = {k: z[k] for k in z.files}
+    ref = O.quanonet_forward(params, bre, tre, 3, (3, 1, 2, 1))
+    pred = s.predict(s.test_input)[:, 0].cpu().numpy()
+    np.testing.assert_allclose(pred, ref, rtol=0, atol=TOL)
+    assert abs(json.load(open(os.path.join(out_dir, 'metric.json')))['metrics']['MSE'] - m['MSE']) < 1e-15
+    # reproducible run-to-run (same seeds -> same history, bitwise)
+    np.random.seed(0); torch.manual_seed(0)
+    cfg2 = dict(cfg, run_id='run1', if_save=False)
+    h2 = PTSolver(cfg2, data, device=dev, log=lambda *a, **k: None).train()
+    assert h2['loss_train'] == hist['loss_train']
+
+
+def test_reference_checkpoint_loads_into_model(dev):
+    """Weights shipped by the reference (decoded .ckpt fixture) -> QuanONetPT via checkpoint.ms_to_pt_state."""
+    from quanonet_amd.checkpoint import ms_to_pt_state
+    from quanonet_amd.models import QuanONetPT
+    st = dict(np.load(H.GOLDEN + '/antideriv_q2.npz'))
+    sd = ms_to_pt_state(st, 2, (5, 1, 5, 1))
+    model = QuanONetPT(2, 10, 1, (5, 1, 5, 1), scale_coeff=0.001, if_trainable_freq=True)
+    model.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    trunk = np.linspace(0, 1, 100)[:, None]
+    branch = np.tile(np.cos(np.pi * np.linspace(0, 1, 10)), (100, 1))
+    with torch.no_grad():
+        out = model(_t(branch, dev), _t(trunk, dev))[:, 0].cpu().numpy()
+    truth = np.sin(np.pi * trunk[:, 0]) / np.pi                     # K1 (ibm_inference.py:180-183)
+    assert np.linalg.norm(out - truth) / np.linalg.norm(truth) < 0.05
