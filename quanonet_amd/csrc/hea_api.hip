@@ -139,32 +139,8 @@ inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 struct Layout {
     size_t off_U, off_cs, off_part, total;
     long nwaves, nwaves_fwd;
-    bool dup, lds_fwd, lds_bwd;
+    bool lds_fwd, lds_bwd;
 };
-
-// psi/lambda-split backward kernel (n <= 5): chosen when even at half the samples per wave the batch does not
-// give every SIMD a wave, i.e. the packed kernel would leave SIMDs idle (hea_device.hpp: bwd_dup_kernel)
-int simd_count() {
-    static int cached = 0;
-    if (cached == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            cached = 4 * cus;
-        else
-            return 1024;                               // MI355X: 256 CUs x 4 SIMDs (used when no device is visible)
-    }
-    return cached;
-}
-bool use_dup(int n, int64_t B) {
-    if (n > 5 || B <= 0) return false;
-    if (const char* e = getenv("QHEA_BACKWARD_KERNEL")) {     // test hook: "packed" / "split" force a variant
-        if (e[0] == 'p') return false;
-        if (e[0] == 's') return true;
-    }
-    const int spwd = 32 >> n;
-    return (B + spwd - 1) / spwd <= simd_count();
-}
 
 // LDS-resident kernels (hea_lds.hip) where the wave-resident ones spill badly: n = 12 (measured, 12 sub-layers,
 // B = 1024: backward 2.5 ms vs 14.5 ms, forward 0.67 vs 0.79 ms; at n = 11 the wave-resident kernels still win)
@@ -182,8 +158,7 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     const int spw_packed = n < 6 ? (64 >> n) : 1;
     L.lds_fwd = use_lds(n, false);
     L.lds_bwd = use_lds(n, true);
-    L.dup = !L.lds_bwd && use_dup(n, B);
-    const int spw = L.lds_bwd ? 1 : (L.dup ? (32 >> n) : spw_packed);
+    const int spw = L.lds_bwd ? 1 : spw_packed;
     auto round_waves = [](long w) { return ((w + kWaves - 1) / kWaves) * kWaves; };   // padding waves write zeros
     L.nwaves_fwd = round_waves((B + spw_packed - 1) / spw_packed);
     L.nwaves = L.lds_bwd ? B : round_waves((B + spw - 1) / spw);                      // backward partial rows
@@ -542,7 +517,7 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
     if (L.lds_bwd) {
         if (launch_lds_bwd(n_qubits, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;
     } else switch (n_qubits) {
-#define QHEA_CASE(NN) case NN: if (L.dup) launch_bwd_dup_##NN(grid, st, ba); else launch_bwd_##NN(grid, st, ba); break;
+#define QHEA_CASE(NN) case NN: launch_bwd_##NN(grid, st, ba); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
         default: return QHEA_EUNSUPPORTED;
@@ -633,7 +608,7 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const doubl
     if (M.L.lds_bwd) {
         if (launch_lds_bwd(mi.n, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;
     } else switch (mi.n) {
-#define QHEA_CASE(NN) case NN: if (M.L.dup) launch_bwd_dup_##NN(grid, st, ba); else launch_bwd_##NN(grid, st, ba); break;
+#define QHEA_CASE(NN) case NN: launch_bwd_##NN(grid, st, ba); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
         default: return QHEA_EUNSUPPORTED;

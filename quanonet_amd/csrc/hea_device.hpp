@@ -30,7 +30,8 @@
 
 namespace qhea {
 
-constexpr int kWaves = 4;              // waves per workgroup (2 was measured 9 % slower at B=1024)
+constexpr int kWaves = 2;              // waves per workgroup: small, so that a small batch spreads over all CUs
+                                       // (LDS and texture paths are per CU); measured at B=1024: 4 -> 218, 2 -> 204, 1 -> 205 us/step
 constexpr int kMaxRuns = 16;           // run-length-encoded (count, enc, ld) block list
 constexpr int kCsPerWave = 512;        // wave-private LDS staging of (cos,sin) pairs: 8 KB per wave
 constexpr int kRedStride = 66;         // doubles per row of the wave-private reduction scratch (64 lanes + pad)
@@ -834,218 +835,6 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
 }
 
 // ---------------------------------------------------------------------------------------
-// psi/lambda-split backward kernel (n <= 5, small batches)
-// ---------------------------------------------------------------------------------------
-// With 2^n <= 32 lanes per sample a wave normally carries two (or more) samples and the reverse sweep
-// updates psi and lambda one after the other.  When the batch is too small to give every SIMD a wave
-// (B = 1024 at Q5 -> 512 waves for 1024 SIMDs) this variant spends a whole wave on HALF as many samples:
-// lanes 0-31 hold psi, lanes 32-63 hold lambda of the same samples, so ONE U-dagger application updates
-// both states, and the psi half fetches its lambda partner with a cross-half gather for the inner
-// products.  Twice the waves, ~2/3 of the reverse-sweep instructions per wave; same arithmetic, same
-// results (summation order differs from the packed kernel only in which lanes hold what).
-template <int K>
-__device__ __forceinline__ void half_sum_put(const double (&v)[K], double* red, int lane, double (&t)[K]) {
-    static_assert(K == 8 || K == 16, "K");
-    constexpr int LPV = 64 / K, EPL = 32 / LPV;       // lanes per value, entries per lane (lanes 0-31 only)
-#pragma unroll
-    for (int j = 0; j < K; ++j) red[j * kRedStride + lane] = v[j];
-    const double* row = red + (lane / LPV) * kRedStride + (lane % LPV) * EPL;
-#pragma unroll
-    for (int i = 0; i < EPL; ++i) t[i] = row[i];
-}
-template <int K>
-__device__ __forceinline__ double half_sum_finish(double (&t)[K]) {
-    constexpr int LPV = 64 / K, EPL = 32 / LPV;
-    double s = t[0];
-#pragma unroll
-    for (int i = 1; i < EPL; ++i) s += t[i];
-    s += xchg<1>(s);
-    s += xchg<2>(s);
-    if constexpr (LPV == 8) s += xchg<4>(s);
-    return s;
-}
-
-template <int N>
-struct GradSumsDup {
-    using C = Cfg<N>;
-    static constexpr int SPWD = 32 >> C::LB;                 // samples per wave
-    static constexpr int PAIRS = SPWD * C::KX;               // (sample, value) pairs of one RX chunk
-    static constexpr int LPP = 64 / PAIRS;                   // lanes per pair (4 or 8)
-    static constexpr int EPL = C::LANES / LPP;               // entries each of them adds
-    static_assert(LPP == 4 || LPP == 8, "LPP");
-    double tw[C::KW], tx[EPL > 0 ? EPL : 1];
-    int sub_w, col_x, m_x;
-    double* red;
-    int lane;
-    long wave, B;
-    int E;
-    double* __restrict__ part_w;
-    double* __restrict__ grad_x;
-
-    __device__ __forceinline__ void flush_w() {
-        if (sub_w >= 0) {
-            const double tot = half_sum_finish<C::KW>(tw);
-            constexpr int LPV = 64 / C::KW;
-            if (lane % LPV == 0) part_w[(long)sub_w * C::KW + lane / LPV] = tot;
-            sub_w = -1;
-        }
-    }
-    __device__ __forceinline__ void flush_x() {
-        if (col_x >= 0) {
-            double s = tx[0];
-#pragma unroll
-            for (int i = 1; i < EPL; ++i) s += tx[i];
-            s += xchg<1>(s);
-            s += xchg<2>(s);
-            if constexpr (LPP == 8) s += xchg<4>(s);
-            const int pidx = lane / LPP, j = pidx % C::KX;
-            const long bs = wave * SPWD + pidx / C::KX;
-            if (lane % LPP == 0 && j < m_x && bs < B) grad_x[bs * E + col_x + j] = s;
-            col_x = -1;
-        }
-    }
-    __device__ __forceinline__ void put_w(const double (&acc3)[C::KW], int sub) {
-        flush_w();
-        half_sum_put<C::KW>(acc3, red, lane, tw);
-        sub_w = sub;
-    }
-    __device__ __forceinline__ void put_x(const double (&gx)[C::KX], int col, int m) {
-        flush_x();
-#pragma unroll
-        for (int j = 0; j < C::KX; ++j) red[j * kRedStride + lane] = gx[j];
-        const int pidx = lane / LPP;
-        const double* row = red + (pidx % C::KX) * kRedStride + (pidx / C::KX) * C::LANES + (lane % LPP) * EPL;
-#pragma unroll
-        for (int i = 0; i < EPL; ++i) tx[i] = row[i];
-        col_x = col; m_x = m;
-    }
-};
-
-template <int N>
-__global__ __launch_bounds__(kWaves * 64) void bwd_dup_kernel(Runs runs, long B, int E, int blk,
-                                                              const double2* __restrict__ cs,
-                                                              const char* __restrict__ gates, int gates_bytes,
-                                                              double off, double co,
-                                                              const double* __restrict__ diag,
-                                                              const double* __restrict__ g,
-                                                              const double* __restrict__ state_in,
-                                                              const double* __restrict__ y,
-                                                              const double* __restrict__ bias,
-                                                              double inv_bt,
-                                                              double* __restrict__ out,
-                                                              double* __restrict__ grad_x,
-                                                              double* __restrict__ partial) {
-    using C = Cfg<N>;
-    static_assert(N <= 5, "psi/lambda split needs 2^n <= 32 lanes per sample");
-    constexpr int SPWD = 32 >> C::LB;
-    __shared__ double2 cs_lds[kWaves * kCsPerWave + 16];
-    __shared__ double red_lds[kWaves * kRedPerWave];
-    __shared__ __attribute__((aligned(16))) char gate_ring[kWaves * kRingBytesPerWave];
-    const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    const bool lam = lane >= 32;
-    const int siw = (lane & 31) >> C::LB;
-    const long wave = (long)blockIdx.x * kWaves + wib;
-    const long b_raw = wave * SPWD + siw;
-    const bool valid = b_raw < B;
-    const long b = valid ? b_raw : B - 1;
-    const int klow = lane & (C::LANES - 1);
-    const int ring_fwd = ring_source<N>(lane, false);
-    const int ring_rev = ring_source<N>(lane, true);
-    const int other_half = (lane ^ 32) << 2;
-
-    CsStream<N> csx;
-    csx.init(cs_lds + wib * kCsPerWave, cs, b, E, lane, siw);
-    GateStream<N> gs;
-    gs.init(gates, gates_bytes, gate_ring + wib * kRingBytesPerWave, lane);
-
-    double sr[1], si[1];
-    if (state_in) {
-        const double2 a = reinterpret_cast<const double2*>(state_in)[(b << N) + klow];
-        sr[0] = a.x; si[0] = a.y;
-    } else {
-        forward_sweep<N>(sr, si, runs, csx, gs, lane, ring_fwd);     // both halves compute the same psi
-    }
-    const double h = ham_weight<N>(klow, off, co, diag);
-    double gb;
-    if (y || out) {
-        double v[1] = {h * (sr[0] * sr[0] + si[0] * si[0])};
-        lane_reduce<1, C::LB>(v, lane);
-        const double pred = v[0] + (bias ? bias[0] : 0.0);
-        if (out && valid && klow == 0 && !lam) out[b] = pred;
-        gb = y ? 2.0 * (pred - y[b]) * inv_bt : g[b];
-    } else {
-        gb = g[b];
-    }
-    if (!valid) gb = 0.0;
-    if (lam) { sr[0] *= gb * h; si[0] *= gb * h; }                   // upper half becomes lambda = g H psi
-
-    GradSumsDup<N> sums;
-    sums.sub_w = -1; sums.col_x = -1; sums.m_x = 0; sums.red = red_lds + wib * kRedPerWave; sums.lane = lane;
-    sums.wave = wave; sums.B = B; sums.E = E; sums.part_w = partial + wave * (long)blk * C::KW; sums.grad_x = grad_x;
-
-    int col = E, sub = blk;
-    gs.template prime<false>(blk - 1);
-    for (int ri = runs.nruns - 1; ri >= 0; --ri) {
-        const int ne = runs.enc[ri], nld = runs.ld[ri];
-        for (int rep = 0; rep < runs.count[ri]; ++rep) {
-            const int nchunks = (ne + N - 1) / N;
-            if (ne > 0) csx.template prefetch<false>(col - (ne - (nchunks - 1) * N));   // last chunk of this block's angles
-            for (int l = nld - 1; l >= 0; --l) {
-                --sub;
-                sr[0] = lane_gather(sr[0], ring_rev);
-                si[0] = lane_gather(si[0], ring_rev);
-                double acc3[C::KW];
-#pragma unroll
-                for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
-                gs.template begin<false>();
-                static_rfor<0, N>([&](auto q) {
-                    constexpr int Q = decltype(q)::value;
-                    const double4 u = gs.template cur<false, Q>();
-                    const double pr = sr[0], pi = si[0];
-                    const double lr = lane_gather(pr, other_half), li = lane_gather(pi, other_half);
-                    const double qr = xchg<(1 << Q)>(pr), qi = xchg<(1 << Q)>(pi);
-                    const double s = ((lane >> Q) & 1) ? -1.0 : 1.0;
-                    acc3[3 * Q] = lr * qi - li * qr;
-                    acc3[3 * Q + 1] = -s * (lr * qr + li * qi);
-                    acc3[3 * Q + 2] = s * (lr * pi - li * pr);
-                    // U-dagger with this lane's variant (ar, s ai, s br, bi) -> (x, -y, -z, -w)
-                    sr[0] = u.x * pr + u.y * pi - u.z * qr + u.w * qi;
-                    si[0] = u.x * pi - u.y * pr - u.z * qi - u.w * qr;
-                    gs.template done<false, Q>();
-                });
-                gs.template advance<false>();
-                sums.put_w(acc3, sub);
-            }
-            col -= ne;
-            for (int ch = nchunks - 1; ch >= 0; --ch) {
-                const int j0 = ch * N;
-                const int m = (ne - j0) < N ? (ne - j0) : N;
-                if (ch != nchunks - 1) csx.template prefetch<false>(col + j0);
-                double gx[C::KX];
-#pragma unroll
-                for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
-                static_rfor<0, N>([&](auto q) {
-                    constexpr int Q = decltype(q)::value;
-                    if (Q < m) {
-                        const double c = csx.nxt[Q].x, sn = csx.nxt[Q].y;
-                        const double pr = sr[0], pi = si[0];
-                        const double lr = lane_gather(pr, other_half), li = lane_gather(pi, other_half);
-                        const double qr = xchg<(1 << Q)>(pr), qi = xchg<(1 << Q)>(pi);
-                        gx[Q] = lr * qi - li * qr;
-                        sr[0] = c * pr - sn * qi;                    // RX(-theta)
-                        si[0] = c * pi + sn * qr;
-                    }
-                });
-                sums.put_x(gx, col + j0, m);
-            }
-        }
-    }
-    sums.flush_w();
-    sums.flush_x();
-}
-
-// ---------------------------------------------------------------------------------------
 // launch entry points; one translation unit per qubit count (hea_inst.hip, -DQHEA_N=n)
 // ---------------------------------------------------------------------------------------
 struct FwdArgs {
@@ -1065,8 +854,7 @@ struct BwdArgs {
 #endif
 #define QHEA_DECLARE(NN)                                              \
     void launch_fwd_##NN(dim3 grid, hipStream_t st, const FwdArgs& a); \
-    void launch_bwd_##NN(dim3 grid, hipStream_t st, const BwdArgs& a); \
-    void launch_bwd_dup_##NN(dim3 grid, hipStream_t st, const BwdArgs& a);   /* n <= 5 only, else a stub */
+    void launch_bwd_##NN(dim3 grid, hipStream_t st, const BwdArgs& a);
 QHEA_FOR_EACH_N(QHEA_DECLARE)
 #undef QHEA_DECLARE
 
