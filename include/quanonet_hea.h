@@ -183,6 +183,16 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch,
                          double* grad /*DEVICE [P+2]*/, double* pred /*DEVICE [B] or NULL*/,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * One Adam update of the flat parameter vector, in place, in ONE launch.  Same arithmetic as
+ * torch.optim.Adam (amsgrad=False, maximize=False; the reference's optimizer, solvers/solver_pt.py:149-163):
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * with g += weight_decay * p first when weight_decay != 0.  `step` is the 1-based update count t.
+ */
+int qhea_adam_step(int64_t n, double* params /*DEVICE*/, const double* grads /*DEVICE*/,
+                   double* exp_avg /*DEVICE*/, double* exp_avg_sq /*DEVICE*/, int64_t step,
+                   double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

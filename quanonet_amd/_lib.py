@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libquanonet_hea.so')
 
 EXPORTS = ['qhea_version', 'qhea_strerror', 'qhea_device_count', 'qhea_workspace_bytes',
            'qhea_forward', 'qhea_backward', 'qhea_model_param_count', 'qhea_model_workspace_bytes',
-           'qhea_model_forward', 'qhea_model_loss_grad', 'qhea_profile_next_circuit_kernel']
+           'qhea_model_forward', 'qhea_model_loss_grad', 'qhea_profile_next_circuit_kernel', 'qhea_adam_step']
 
 
 class ModelDesc(ctypes.Structure):
@@ -61,6 +61,9 @@ def load():
                                   vp, ctypes.c_size_t, vp]
     lib.qhea_profile_next_circuit_kernel.restype = ctypes.c_int
     lib.qhea_profile_next_circuit_kernel.argtypes = [vp, vp]
+    lib.qhea_adam_step.restype = ctypes.c_int
+    lib.qhea_adam_step.argtypes = [ctypes.c_int64, dp, dp, dp, dp, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
+                                   ctypes.c_double, ctypes.c_double, ctypes.c_double, vp]
     mdp = ctypes.POINTER(ModelDesc)
     lib.qhea_model_param_count.restype = ctypes.c_int64
     lib.qhea_model_param_count.argtypes = [mdp]
@@ -238,3 +241,17 @@ def profile_next_circuit_kernel(start_event, stop_event):
     rc = load().qhea_profile_next_circuit_kernel(ctypes.c_void_p(start_event.cuda_event),
                                                  ctypes.c_void_p(stop_event.cuda_event))
     _check(rc, 'qhea_profile_next_circuit_kernel')
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """In-place Adam update of the flat fp64 parameter vector (one launch); grads may be a longer buffer."""
+    n = params.numel()
+    for t, nm in ((params, 'params'), (grads, 'grads'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
+        _dev_f64(t, nm)
+    if grads.numel() < n or exp_avg.numel() != n or exp_avg_sq.numel() != n:
+        raise QheaError("adam_step: buffer sizes do not match the parameter vector")
+    with torch.cuda.device(params.device):
+        rc = load().qhea_adam_step(n, _ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), int(step),
+                                   float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                   _stream(params.device))
+    _check(rc, 'qhea_adam_step')

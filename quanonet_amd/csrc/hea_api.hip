@@ -1,5 +1,6 @@
 // hea_api.hip -- C ABI (include/quanonet_hea.h) of the MI355X HEA simulator: argument checks,
 // workspace layout, the batch-invariant prep / reduce kernels and the per-qubit-count dispatch.
+#include <cmath>
 #include <cstdlib>
 
 #include "hea_device.hpp"
@@ -168,6 +169,21 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     L.off_part = p; p = align_up(p + (size_t)L.nwaves * sh.blk * padded_3n(n) * sizeof(double));
     L.total = p;
     return L;
+}
+
+__global__ void adam_kernel(long n, double* __restrict__ p, const double* __restrict__ g, double* __restrict__ m,
+                            double* __restrict__ v, double lr_over_bc1, double inv_sqrt_bc2, double b1, double b2,
+                            double eps, double wd) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double gi = g[i];
+    const double pi = p[i];
+    if (wd != 0.0) gi += wd * pi;
+    const double mi = b1 * m[i] + (1.0 - b1) * gi;           // torch: exp_avg.lerp_(grad, 1 - beta1)
+    const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;      //        exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[i] = mi; v[i] = vi;
+    const double denom = sqrt(vi) * inv_sqrt_bc2 + eps;
+    p[i] = pi - lr_over_bc1 * (mi / denom);
 }
 
 thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
@@ -624,6 +640,18 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const doubl
     hipLaunchKernelGGL(reduce_model_kernel, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
                        (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
                        gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad);
+    return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+}
+
+int qhea_adam_step(int64_t n, double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t step,
+                   double lr, double beta1, double beta2, double eps, double weight_decay, void* stream) {
+    if (n < 0 || step < 1) return QHEA_EINVAL;
+    if (n == 0) return QHEA_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq) return QHEA_EINVAL;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (long)n, params, grads, exp_avg, exp_avg_sq, lr / bc1, 1.0 / sqrt(bc2), beta1, beta2, eps,
+                       weight_decay);
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 

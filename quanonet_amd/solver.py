@@ -28,6 +28,43 @@ def shard_slice(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class FlatAdam(torch.optim.Optimizer):
+    """
+    torch.optim.Adam arithmetic (amsgrad=False) on the trainer's flat fp64 vector through ``qhea_adam_step``:
+    one launch per update instead of torch's two multi-tensor kernels.  A regular ``Optimizer`` (param_groups,
+    lr schedulers, state_dict) so that PTSolver's scheduler handling is unchanged.
+    """
+
+    def __init__(self, params, pflat, gflat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(list(params), dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.pflat, self.gflat = pflat, gflat
+        self.exp_avg = torch.zeros_like(pflat)
+        self.exp_avg_sq = torch.zeros_like(pflat)
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _lib
+        g = self.param_groups[0]
+        self.t += 1
+        _lib.adam_step(self.pflat, self.gflat, self.exp_avg, self.exp_avg_sq, self.t, g['lr'], g['betas'][0],
+                       g['betas'][1], g['eps'], g['weight_decay'])
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd['flat_state'] = {'step': self.t, 'exp_avg': self.exp_avg.clone(), 'exp_avg_sq': self.exp_avg_sq.clone()}
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        fs = sd.pop('flat_state', None)
+        super().load_state_dict(sd)
+        if fs is not None:
+            self.t = int(fs['step'])
+            self.exp_avg.copy_(fs['exp_avg'])
+            self.exp_avg_sq.copy_(fs['exp_avg_sq'])
+
+
 class DataParallelTrainer:
     """
     fused='auto': when the model is one of this package's QuanONetPT / HEAQNNPT (fp64, on a HIP
@@ -70,9 +107,12 @@ class DataParallelTrainer:
         opt_map = {'adam': torch.optim.Adam, 'adamw': torch.optim.AdamW, 'sgd': torch.optim.SGD,
                    'rmsprop': torch.optim.RMSprop}
         cls = opt_map.get(optimizer.lower(), torch.optim.Adam)
-        if cls in (torch.optim.Adam, torch.optim.AdamW) and p0.is_cuda and 'fused' not in kw:
-            kw['fused'] = True
-        self.optimizer = cls(self.params, lr=lr, **kw)
+        if cls is torch.optim.Adam and p0.is_cuda and set(kw) <= {'betas', 'eps', 'weight_decay'}:
+            self.optimizer = FlatAdam(self.params, self.pflat, self.flat, lr=lr, **kw)     # one launch per update
+        else:
+            if cls in (torch.optim.Adam, torch.optim.AdamW) and p0.is_cuda and 'fused' not in kw:
+                kw['fused'] = True
+            self.optimizer = cls(self.params, lr=lr, **kw)
         if self.world > 1:
             self.broadcast_parameters()
 

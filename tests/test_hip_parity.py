@@ -304,3 +304,23 @@ def test_reference_checkpoint_loads_into_model(dev):
         out = model(_t(branch, dev), _t(trunk, dev))[:, 0].cpu().numpy()
     truth = np.sin(np.pi * trunk[:, 0]) / np.pi                     # K1 (ibm_inference.py:180-183)
     assert np.linalg.norm(out - truth) / np.linalg.norm(truth) < 0.05
+
+
+def test_flat_adam_equals_torch_adam(dev):
+    from quanonet_amd.solver import FlatAdam
+    rng = np.random.default_rng(1)
+    n = 2401
+    p0 = _t(rng.normal(size=n), dev)
+    pa, pb = p0.clone(), p0.clone().requires_grad_(True)
+    ga = torch.zeros(n + 2, dtype=torch.float64, device=dev)
+    flat = FlatAdam([torch.nn.Parameter(pa)], pa, ga, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    ref = torch.optim.Adam([pb], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for it in range(25):
+        g = _t(rng.normal(size=n) * (1.0 + it), dev)
+        ga[:n] = g
+        pb.grad = g.clone()
+        flat.step(); ref.step()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pa.cpu().numpy(), pb.detach().cpu().numpy(), rtol=1e-13, atol=1e-15)
+    sd = flat.state_dict()
+    assert sd['flat_state']['step'] == 25
