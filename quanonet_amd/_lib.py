@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libquanonet_hea.so')
+LIB_PATH = os.environ.get('QHEA_LIB') or os.path.join(_HERE, 'libquanonet_hea.so')   # QHEA_LIB: ablation/dev builds
 
 EXPORTS = ['qhea_version', 'qhea_strerror', 'qhea_device_count', 'qhea_workspace_bytes',
            'qhea_forward', 'qhea_backward', 'qhea_model_param_count', 'qhea_model_workspace_bytes',

@@ -307,6 +307,9 @@ template <int N, bool REVERSE>
 __device__ __forceinline__ void apply_ring(double (&re)[Cfg<N>::R], double (&im)[Cfg<N>::R],
                                            int lane, int ring_src_x4) {
     using C = Cfg<N>;
+#ifdef QHEA_ABLATE_RING
+    return;
+#endif
     if constexpr (C::RB == 0) {                        // whole state on lanes: one gather
         re[0] = lane_gather(re[0], ring_src_x4);
         im[0] = lane_gather(im[0], ring_src_x4);
@@ -336,6 +339,10 @@ __device__ __forceinline__ void pauli_inner(const double (&pr)[Cfg<N>::R], const
                                             int lane, double& X, double& Y, double& Z) {
     using C = Cfg<N>;
     double x = 0.0, y = 0.0, z = 0.0;
+#ifdef QHEA_ABLATE_INNER
+    X = lr[0]; Y = li[0]; Z = pr[0];
+    return;
+#endif
     if constexpr (Q < C::LB) {
 #pragma unroll
         for (int r = 0; r < C::R; ++r) {
@@ -572,11 +579,21 @@ struct GradSums {
         }
     }
     __device__ __forceinline__ void put_w(const double (&acc3)[C::KW], int sub) {
+#ifdef QHEA_ABLATE_SUMS
+        double a = 0; for (int i = 0; i < C::KW; ++i) a += acc3[i];
+        asm volatile("" :: "v"(a));
+        return;
+#endif
         flush_w();
         wave_sum_put<C::KW>(acc3, red, lane, tw);
         sub_w = sub;
     }
     __device__ __forceinline__ void put_x(const double (&gx)[C::KX], int col, int m) {
+#ifdef QHEA_ABLATE_SUMS
+        double a = 0; for (int i = 0; i < C::KX; ++i) a += gx[i];
+        asm volatile("" :: "v"(a));
+        return;
+#endif
         flush_x();
         sample_sum_put<C::KX, C::LB>(gx, red, lane, tx);
         col_x = col; m_x = m;

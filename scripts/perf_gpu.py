@@ -43,6 +43,8 @@ if __name__ == '__main__':
         case(5, O.block_configs_quanonet(5, (40, 2, 20, 2)), 1024)
         case(5, O.block_configs_quanonet(5, (40, 2, 20, 2)), 4096, check=False)
         case(5, O.block_configs_quanonet(5, (40, 2, 20, 2)), 16384, check=False)
+    if 'cfg2nocheck' in which:
+        case(5, O.block_configs_quanonet(5, (40, 2, 20, 2)), 1024, check=False)
     if 'cfg1' in which:
         case(2, O.block_configs_quanonet(2, (5, 1, 5, 1)), 32)
         case(2, O.block_configs_quanonet(2, (5, 1, 5, 1)), 4096, check=False)
