@@ -324,3 +324,24 @@ def test_flat_adam_equals_torch_adam(dev):
     np.testing.assert_allclose(pa.cpu().numpy(), pb.detach().cpu().numpy(), rtol=1e-13, atol=1e-15)
     sd = flat.state_dict()
     assert sd['flat_state']['step'] == 25
+
+
+def test_float32_module_like_the_reference(dev):
+    """The reference keeps float32 parameters/inputs (solver_pt.py:132); the op computes in fp64 and casts back."""
+    from quanonet_amd.models import QuanONetPT
+    torch.manual_seed(5)
+    n, net = 3, (2, 1, 2, 2)
+    model = QuanONetPT(n, 6, 2, net, scale_coeff=0.1, if_trainable_freq=True, dtype=torch.float32).to(dev)
+    rng = np.random.default_rng(8)
+    br = rng.normal(size=(20, 6)).astype(np.float32); tr = rng.uniform(size=(20, 2)).astype(np.float32)
+    y = rng.normal(size=(20, 1)).astype(np.float32)
+    out = model(torch.tensor(br, device=dev), torch.tensor(tr, device=dev))
+    assert out.dtype == torch.float32 and out.shape == (20, 1)
+    loss = torch.nn.functional.mse_loss(out, torch.tensor(y, device=dev))
+    loss.backward()
+    params = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in model.state_dict().items()}
+    rl, rg, ro = O.quanonet_loss_and_grads(params, br.astype(np.float64), tr.astype(np.float64), y[:, 0].astype(np.float64), n, net)
+    np.testing.assert_allclose(out[:, 0].detach().cpu().numpy(), ro, rtol=0, atol=2e-5)     # float32 pre/post-processing
+    for k, p in model.named_parameters():
+        assert p.grad.dtype == torch.float32
+        np.testing.assert_allclose(p.grad.cpu().numpy().reshape(-1), rg[k].reshape(-1), rtol=0, atol=2e-5, err_msg=k)
