@@ -140,8 +140,32 @@ inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 struct Layout {
     size_t off_U, off_cs, off_part, total;
     long nwaves, nwaves_fwd;
-    bool lds_fwd, lds_bwd;
+    bool lds_fwd, lds_bwd, pair;
 };
+
+// Wave-pair pipelined backward kernel (n <= 5): two waves per sample group, so it pays while the packed kernel
+// would leave at least half of the SIMDs without a wave (hea_device.hpp: bwd_pair_kernel)
+int simd_count() {
+    static int cached = 0;
+    if (cached == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            cached = 4 * cus;
+        else
+            return 1024;                               // MI355X: 256 CUs x 4 SIMDs (used when no device is visible)
+    }
+    return cached;
+}
+bool use_pair(int n, int64_t B) {
+    if (n > 5 || B <= 0) return false;
+    if (const char* e = getenv("QHEA_BACKWARD_KERNEL")) {     // test hook: "packed" / "pair" force a variant
+        if (e[0] == 'p' && e[1] == 'a' && e[2] == 'c') return false;
+        if (e[0] == 'p' && e[1] == 'a' && e[2] == 'i') return true;
+    }
+    const int spw = 64 >> n;
+    return 2 * ((B + spw - 1) / spw) <= simd_count();
+}
 
 // LDS-resident kernels (hea_lds.hip) where the wave-resident ones spill badly: n = 12 (measured, 12 sub-layers,
 // B = 1024: backward 2.5 ms vs 14.5 ms, forward 0.67 vs 0.79 ms; at n = 11 the wave-resident kernels still win)
@@ -159,10 +183,12 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     const int spw_packed = n < 6 ? (64 >> n) : 1;
     L.lds_fwd = use_lds(n, false);
     L.lds_bwd = use_lds(n, true);
+    L.pair = !L.lds_bwd && use_pair(n, B);
     const int spw = L.lds_bwd ? 1 : spw_packed;
     auto round_waves = [](long w) { return ((w + kWaves - 1) / kWaves) * kWaves; };   // padding waves write zeros
     L.nwaves_fwd = round_waves((B + spw_packed - 1) / spw_packed);
     L.nwaves = L.lds_bwd ? B : round_waves((B + spw - 1) / spw);                      // backward partial rows
+    if (L.pair) L.nwaves = (B + spw - 1) / spw;                                       // one row per workgroup (= sample group)
     size_t p = 0;
     L.off_U = p;    p = align_up(p + (size_t)(sh.blk + 2) * n * kGateBytes);
     L.off_cs = p;   p = align_up(p + (size_t)B * sh.E * sizeof(double2));
@@ -533,7 +559,7 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
     if (L.lds_bwd) {
         if (launch_lds_bwd(n_qubits, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;
     } else switch (n_qubits) {
-#define QHEA_CASE(NN) case NN: launch_bwd_##NN(grid, st, ba); break;
+#define QHEA_CASE(NN) case NN: if (L.pair) launch_bwd_pair_##NN(dim3((unsigned)L.nwaves), st, ba); else launch_bwd_##NN(grid, st, ba); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
         default: return QHEA_EUNSUPPORTED;
@@ -624,7 +650,7 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const doubl
     if (M.L.lds_bwd) {
         if (launch_lds_bwd(mi.n, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;
     } else switch (mi.n) {
-#define QHEA_CASE(NN) case NN: launch_bwd_##NN(grid, st, ba); break;
+#define QHEA_CASE(NN) case NN: if (M.L.pair) launch_bwd_pair_##NN(dim3((unsigned)M.L.nwaves), st, ba); else launch_bwd_##NN(grid, st, ba); break;
         QHEA_FOR_EACH_N(QHEA_CASE)
 #undef QHEA_CASE
         default: return QHEA_EUNSUPPORTED;

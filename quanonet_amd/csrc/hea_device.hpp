@@ -852,6 +852,229 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
 }
 
 // ---------------------------------------------------------------------------------------
+// wave-pair pipelined backward kernel (n <= 5, small batches)
+// ---------------------------------------------------------------------------------------
+// Facts it is built on (profiles/): one wave issues roughly one instruction per 4-5 cycles, a
+// SIMD is saturated by a single wave, and at B = 1024 (Q5) the packed kernel only occupies half of the
+// chip's SIMDs.  The reverse sweep is two dependent chains that share no arithmetic: psi is un-computed
+// (it never needs lambda), lambda is pulled back and meets psi only in the inner products.  So a
+// workgroup is TWO waves working on the same samples:
+//   wave 0 ("psi wave"):    forward sweep, publishes psi_N, then walks psi backwards and publishes the
+//                           state after every sub-layer's gates / every RX phase into a small LDS ring;
+//   wave 1 ("lambda wave"): waits for psi_N, forms lambda_N = g H psi_N, walks lambda backwards; per
+//                           sub-layer it reads ONE published psi (own amplitude + the n partners straight
+//                           from LDS, no DPP), takes all 3n inner products against the not-yet-evolved
+//                           lambda (gates of a sub-layer commute), then applies the n U-daggers to lambda.
+// The psi wave runs ahead (it has ~1/3 of the work), the lambda wave is the critical path with ~70 % of the
+// packed kernel's reverse-sweep instructions.  Hand-off = monotonic counters in LDS with workgroup-scope
+// release/acquire; every spin is bounded (an overrun raises `abort` in LDS and both waves run out).
+constexpr int kPairRing = 16;                // published psi snapshots in flight (16 KB)
+constexpr int kSpinLimit = 1 << 24;
+
+struct PairSync {
+    int produced, consumed, ready, abort;
+};
+
+// Wait until *counter >= target.  `seen` caches the last value read, so the common case (the other wave is
+// already far enough) costs no LDS access at all.
+__device__ __forceinline__ bool pair_wait_ge(int* counter, int target, int* abort_flag, int& seen) {
+    if (seen >= target) return true;
+    for (int it = 0; it < kSpinLimit; ++it) {
+        seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (seen >= target) return true;
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return false;
+}
+
+template <int N>
+__global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E, int blk,
+                                                       const double2* __restrict__ cs,
+                                                       const char* __restrict__ gates, int gates_bytes,
+                                                       double off, double co,
+                                                       const double* __restrict__ diag,
+                                                       const double* __restrict__ g,
+                                                       const double* __restrict__ state_in,
+                                                       const double* __restrict__ y,
+                                                       const double* __restrict__ bias,
+                                                       double inv_bt,
+                                                       double* __restrict__ out,
+                                                       double* __restrict__ grad_x,
+                                                       double* __restrict__ partial) {
+    using C = Cfg<N>;
+    static_assert(C::R == 1 && C::LDSRED, "wave-pair kernel: all-lane layout, n <= 5");
+    __shared__ double2 cs_lds[2 * kCsPerWave + 16];
+    __shared__ double red_lds[kRedPerWave];
+    __shared__ __attribute__((aligned(16))) char gate_ring[2 * kRingBytesPerWave];
+    __shared__ double2 psi_ring[kPairRing][64];
+    __shared__ double2 psi_final[64];
+    __shared__ PairSync sync;
+
+    const int lane = threadIdx.x & 63;
+    const int role = threadIdx.x >> 6;                  // 0: psi wave, 1: lambda wave
+    const long wave = blockIdx.x;                       // one sample group per workgroup
+    const long b_raw = wave * C::SPW + (lane >> C::LB);
+    const bool valid = b_raw < B;
+    const long b = valid ? b_raw : B - 1;
+    const int klow = lane & (C::LANES - 1);
+    const int ring_fwd = ring_source<N>(lane, false);
+    const int ring_rev = ring_source<N>(lane, true);
+
+    if (threadIdx.x == 0) { sync.produced = 0; sync.consumed = 0; sync.ready = 0; sync.abort = 0; }
+    __syncthreads();
+
+    CsStream<N> csx;
+    csx.init(cs_lds + role * kCsPerWave, cs, b, E, lane, lane >> C::LB);
+    GateStream<N> gs;
+    gs.init(gates, gates_bytes, gate_ring + role * kRingBytesPerWave, lane);
+
+    if (role == 0) {
+        // ------------------------------------------------------------------ psi wave
+        double pr[1], pi[1];
+        if (state_in) {
+            const double2 a = reinterpret_cast<const double2*>(state_in)[(b << N) + klow];
+            pr[0] = a.x; pi[0] = a.y;
+        } else {
+            forward_sweep<N>(pr, pi, runs, csx, gs, lane, ring_fwd);
+        }
+        psi_final[lane] = make_double2(pr[0], pi[0]);
+        __hip_atomic_store(&sync.ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+        int col = E, step = 0, seen = 0;
+        bool ok = true;
+        auto publish = [&]() {
+            if (step >= kPairRing) ok = ok && pair_wait_ge(&sync.consumed, step - kPairRing + 1, &sync.abort, seen);
+            psi_ring[step % kPairRing][lane] = make_double2(pr[0], pi[0]);
+            ++step;
+            __hip_atomic_store(&sync.produced, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        gs.template prime<false>(blk - 1);
+        for (int ri = runs.nruns - 1; ri >= 0 && ok; --ri) {
+            const int ne = runs.enc[ri], nld = runs.ld[ri];
+            const int nchunks = (ne + N - 1) / N;
+            for (int rep = 0; rep < runs.count[ri] && ok; ++rep) {
+                if (ne > 0) csx.template prefetch<false>(col - (ne - (nchunks - 1) * N));
+                for (int l = nld - 1; l >= 0; --l) {
+                    apply_ring<N, true>(pr, pi, lane, ring_rev);
+                    publish();                                           // psi after this sub-layer's gates
+                    gs.template begin<false>();
+                    static_rfor<0, N>([&](auto q) {
+                        constexpr int Q = decltype(q)::value;
+                        const double4 u = gs.template cur<false, Q>();
+                        apply_su2<N, Q>(pr, pi, u.x, -u.y, -u.z, -u.w);
+                        gs.template done<false, Q>();
+                    });
+                    gs.template advance<false>();
+                }
+                col -= ne;
+                if (ne > 0) {
+                    publish();                                           // psi after this block's RX phase
+                    for (int ch = nchunks - 1; ch >= 0; --ch) {
+                        const int j0 = ch * N;
+                        const int m = (ne - j0) < N ? (ne - j0) : N;
+                        if (ch != nchunks - 1) csx.template prefetch<false>(col + j0);
+                        static_rfor<0, N>([&](auto q) {
+                            constexpr int Q = decltype(q)::value;
+                            if (Q < m) apply_rx<N, Q>(pr, pi, csx.nxt[Q].x, -csx.nxt[Q].y);
+                        });
+                    }
+                }
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ lambda wave
+        int seen_ready = 0, seen = 0;
+        bool ok = pair_wait_ge(&sync.ready, 1, &sync.abort, seen_ready);
+        const double2 pN = psi_final[lane];
+        const double h = ham_weight<N>(klow, off, co, diag);
+        double gb;
+        {
+            double v[1] = {h * (pN.x * pN.x + pN.y * pN.y)};
+            lane_reduce<1, C::LB>(v, lane);
+            const double pred = v[0] + (bias ? bias[0] : 0.0);
+            if (out && valid && klow == 0) out[b] = pred;
+            gb = y ? 2.0 * (pred - y[b]) * inv_bt : g[b];
+        }
+        if (!valid) gb = 0.0;
+        double lr[1] = {gb * h * pN.x}, li[1] = {gb * h * pN.y};
+
+        GradSums<N> sums;
+        sums.sub_w = -1; sums.col_x = -1; sums.m_x = 0; sums.red = red_lds; sums.lane = lane; sums.wave = wave;
+        sums.B = B; sums.E = E; sums.part_w = partial + wave * (long)blk * C::KW; sums.grad_x = grad_x;
+
+        int col = E, sub = blk, step = 0;
+        gs.template prime<false>(blk - 1);
+        for (int ri = runs.nruns - 1; ri >= 0 && ok; --ri) {
+            const int ne = runs.enc[ri], nld = runs.ld[ri];
+            const int nchunks = (ne + N - 1) / N;
+            for (int rep = 0; rep < runs.count[ri] && ok; ++rep) {
+                if (ne > 0) csx.template prefetch<false>(col - (ne - (nchunks - 1) * N));
+                for (int l = nld - 1; l >= 0; --l) {
+                    --sub;
+                    apply_ring<N, true>(lr, li, lane, ring_rev);
+                    ok = ok && pair_wait_ge(&sync.produced, step + 1, &sync.abort, seen);
+                    const double2* slot = psi_ring[step % kPairRing];
+                    const double2 p = slot[lane];
+                    double2 qv[N];
+                    static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
+                    ++step;
+                    __hip_atomic_store(&sync.consumed, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    double acc3[C::KW];
+#pragma unroll
+                    for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
+                    static_for<0, N>([&](auto q) {                       // all against the not-yet-evolved lambda
+                        constexpr int Q = decltype(q)::value;
+                        const double s = ((lane >> Q) & 1) ? -1.0 : 1.0;
+                        acc3[3 * Q] = lr[0] * qv[Q].y - li[0] * qv[Q].x;
+                        acc3[3 * Q + 1] = -s * (lr[0] * qv[Q].x + li[0] * qv[Q].y);
+                        acc3[3 * Q + 2] = s * (lr[0] * p.y - li[0] * p.x);
+                    });
+                    gs.template begin<false>();
+                    static_rfor<0, N>([&](auto q) {
+                        constexpr int Q = decltype(q)::value;
+                        const double4 u = gs.template cur<false, Q>();
+                        apply_su2<N, Q>(lr, li, u.x, -u.y, -u.z, -u.w);
+                        gs.template done<false, Q>();
+                    });
+                    gs.template advance<false>();
+                    sums.put_w(acc3, sub);
+                }
+                col -= ne;
+                if (ne > 0) {
+                    ok = ok && pair_wait_ge(&sync.produced, step + 1, &sync.abort, seen);
+                    const double2* slot = psi_ring[step % kPairRing];
+                    double2 qv[N];
+                    static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
+                    ++step;
+                    __hip_atomic_store(&sync.consumed, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    double gx[C::KX];
+#pragma unroll
+                    for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
+                    static_for<0, N>([&](auto q) {                       // every RX of the phase commutes with X_q
+                        constexpr int Q = decltype(q)::value;
+                        if (Q < ne) gx[Q] = lr[0] * qv[Q].y - li[0] * qv[Q].x;
+                    });
+                    for (int ch = nchunks - 1; ch >= 0; --ch) {
+                        const int j0 = ch * N;
+                        const int m = (ne - j0) < N ? (ne - j0) : N;
+                        if (ch != nchunks - 1) csx.template prefetch<false>(col + j0);
+                        static_rfor<0, N>([&](auto q) {
+                            constexpr int Q = decltype(q)::value;
+                            if (Q < m) apply_rx<N, Q>(lr, li, csx.nxt[Q].x, -csx.nxt[Q].y);
+                        });
+                        sums.put_x(gx, col + j0, m);                     // wires repeat across chunks with equal gradients
+                    }
+                }
+            }
+        }
+        sums.flush_w();
+        sums.flush_x();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // launch entry points; one translation unit per qubit count (hea_inst.hip, -DQHEA_N=n)
 // ---------------------------------------------------------------------------------------
 struct FwdArgs {
@@ -871,7 +1094,8 @@ struct BwdArgs {
 #endif
 #define QHEA_DECLARE(NN)                                              \
     void launch_fwd_##NN(dim3 grid, hipStream_t st, const FwdArgs& a); \
-    void launch_bwd_##NN(dim3 grid, hipStream_t st, const BwdArgs& a);
+    void launch_bwd_##NN(dim3 grid, hipStream_t st, const BwdArgs& a); \
+    void launch_bwd_pair_##NN(dim3 grid, hipStream_t st, const BwdArgs& a);   /* n <= 5 only, else a stub */
 QHEA_FOR_EACH_N(QHEA_DECLARE)
 #undef QHEA_DECLARE
 

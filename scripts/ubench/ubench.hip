@@ -71,8 +71,8 @@ int run(const char* name, int per_iter) {
     double* out; unsigned long long* cyc;
     CHECK(hipMalloc(&out, sizeof(double) * 256 * 8 * 1024));
     CHECK(hipMalloc(&cyc, sizeof(unsigned long long) * 4 * 8 * 1024));
-    for (int wps : {1, 2, 4, 8}) {          // waves per SIMD: block = 256 threads (1 wave per SIMD), wps blocks per CU
-        const int blocks = 256 * wps;       // all CUs
+    for (int wps : {-16, -4, -2, 1, 2, 4, 8}) {   // >0: waves per SIMD on all 256 CUs; <0: only 256/|wps| blocks (1 wave per SIMD on a fraction of the CUs)
+        const int blocks = wps > 0 ? 256 * wps : 256 / (-wps);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.0000001, 1e-9);
         hipEventRecord(e0);

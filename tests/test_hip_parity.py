@@ -35,7 +35,15 @@ def _run(n, cfgs, x, w, g, dev, off, co, diag=None, use_state=True):
     return (out.cpu().numpy(), st.cpu().numpy(), gx.cpu().numpy(), gw.cpu().numpy(), out2.cpu().numpy())
 
 
-def test_golden_vectors(dev):
+@pytest.fixture(params=['packed', 'pair'])
+def backward_variant(request, monkeypatch):
+    """Both backward kernels for n <= 5 (one wave per sample group vs the psi-wave / lambda-wave pipeline);
+    the library reads the variable at every call."""
+    monkeypatch.setenv('QHEA_BACKWARD_KERNEL', request.param)
+    return request.param
+
+
+def test_golden_vectors(dev, backward_variant):
     for nm, v in H.golden_vectors().items():
         off, co = O.ham_params(v['n'])
         for use_state in (True, False):
@@ -48,7 +56,9 @@ def test_golden_vectors(dev):
 
 
 @pytest.mark.parametrize('n', list(range(2, 13)))
-def test_every_qubit_count_against_oracle(dev, n):
+def test_every_qubit_count_against_oracle(dev, n, backward_variant):
+    if n > 5 and backward_variant == 'pair':
+        pytest.skip("wave-pair kernel exists for n <= 5 only")
     rng = np.random.default_rng(100 + n)
     cfgs = [(n, 2), (n, 1), (n, 2)]
     E, blk = O.circuit_sizes(n, cfgs)
@@ -104,7 +114,7 @@ def test_ham_diag_readout(dev):
     np.testing.assert_allclose(gw, rgw, atol=TOL)
 
 
-def test_edge_shapes(dev):
+def test_edge_shapes(dev, backward_variant):
     from quanonet_amd import _lib
     # batch 1, a block with no ansatz sub-layer, a block with no encoding, more encodings than wires
     for n, cfgs, B in [(5, [(5, 2)], 1), (3, [(3, 0), (3, 1)], 4), (4, [(0, 2), (4, 1)], 5), (2, [(5, 1), (3, 2)], 6)]:
@@ -178,7 +188,7 @@ def test_model_grads_match_oracle(dev):
 
 @pytest.mark.parametrize('n,net,tf', [(5, (3, 2, 2, 1), True), (2, (5, 1, 5, 1), True), (5, (2, 2, 2, 2), False),
                                       (8, (2, 1, 1, 2), True)])
-def test_fused_model_path_matches_oracle_and_autograd(dev, n, net, tf):
+def test_fused_model_path_matches_oracle_and_autograd(dev, n, net, tf, backward_variant):
     """qhea_model_loss_grad / qhea_model_forward == oracle == the autograd module path."""
     from quanonet_amd.models import QuanONetPT
     from quanonet_amd.solver import DataParallelTrainer
