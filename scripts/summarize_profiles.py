@@ -6,14 +6,15 @@ src = f'gpurun_out/prof_{tag}'
 os.makedirs('profiles', exist_ok=True)
 bench = json.loads(open(f'{src}/bench.json').read().strip().splitlines()[-1])
 json.dump(bench, open(f'profiles/{tag}_bench.json', 'w'), indent=1)
-stats = glob.glob(f'{src}/trace/*/*_kernel_stats.csv')[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # gpurun merges runs: take the latest
+stats = newest(f'{src}/trace/*/*_kernel_stats.csv')
 rows = list(csv.DictReader(open(stats)))
 with open(f'profiles/{tag}_bench_kernel_stats.csv', 'w') as f:
     w = csv.writer(f); w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage'])
     for r in rows:
         w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage']])
 def pmc(sub, counter):
-    f = glob.glob(f'{src}/{sub}/*/*counter_collection.csv')[0]
+    f = newest(f'{src}/{sub}/*/*counter_collection.csv')
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == counter:
