@@ -35,7 +35,7 @@ constexpr int kWaves = 2;              // waves per workgroup: small, so that a 
 constexpr int kMaxRuns = 16;           // run-length-encoded (count, enc, ld) block list
 constexpr int kCsPerWave = 512;        // wave-private LDS staging of (cos,sin) pairs: 8 KB per wave
 constexpr int kRedStride = 66;         // doubles per row of the wave-private reduction scratch (64 lanes + pad)
-constexpr int kRedPerWave = 16 * kRedStride;
+constexpr int kRedPerWave = 16 * kRedStride;   // n <= 5 (wave-pair kernel); the packed kernel sizes it by Cfg<N>::REDW
 constexpr int kGateBytes = 64;         // one gate-table entry: 2 lane variants x (ar, s*ai, s*br, bi)
 
 struct Runs {
@@ -57,7 +57,10 @@ struct Cfg {
     static constexpr int CAP = kCsPerWave / SPW;    // staged encoding columns per sample
     static constexpr int UD = (N <= 6) ? N : 1;     // gate-coefficient prefetch distance (gates)
     static constexpr bool LDSRED = N <= 5;          // gradient sums through LDS (few instructions) instead of the
-                                                    // register butterfly (whose cost only amortises for long gates)
+                                                    // register butterfly.  Measured for n = 8 (K = 32, 17 KB of scratch
+                                                    // per wave): the LDS footprint halves the resident waves at
+                                                    // B = 2048 and the backward kernel gets 2x slower -> butterfly there.
+    static constexpr int REDW = KW * 66;            // doubles of wave-private reduction scratch (rows of kRedStride)
 };
 
 __host__ __device__ constexpr int padded_3n(int n) {
@@ -150,7 +153,7 @@ __device__ __forceinline__ void lane_reduce(double (&v)[K], int lane) {
 // wave_sum: every lane contributes v[0..K); lane l ends with the 64-lane total of value l / (64/K).
 template <int K>
 __device__ __forceinline__ void wave_sum_put(const double (&v)[K], double* red, int lane, double (&t)[K]) {
-    static_assert(K == 8 || K == 16, "K");
+    static_assert(K == 8 || K == 16 || K == 32, "K");
     constexpr int LPV = 64 / K;                       // lanes sharing one value
 #pragma unroll
     for (int j = 0; j < K; ++j) red[j * kRedStride + lane] = v[j];
@@ -170,8 +173,8 @@ template <int K>
 __device__ __forceinline__ double wave_sum_finish(double (&t)[K]) {
     double s = tree_sum<K>(t);
     s += xchg<1>(s);
-    s += xchg<2>(s);
-    if constexpr (64 / K == 8) s += xchg<4>(s);
+    if constexpr (64 / K >= 4) s += xchg<2>(s);
+    if constexpr (64 / K >= 8) s += xchg<4>(s);
     return s;
 }
 // sample_sum: every lane contributes v[0..K); a wave holds 64>>LB samples of 2^LB lanes.  Lane l ends
@@ -180,7 +183,7 @@ template <int K, int LB>
 __device__ __forceinline__ void sample_sum_put(const double (&v)[K], double* red, int lane, double (&t)[K]) {
     constexpr int LANES = 1 << LB;
     constexpr int LPP = LANES / K;                    // lanes sharing one (sample, value) pair; each sums K entries
-    static_assert(LPP >= 1 && LPP <= 4, "LPP");
+    static_assert(LPP >= 1 && LPP <= 8, "LPP");
 #pragma unroll
     for (int j = 0; j < K; ++j) red[j * kRedStride + lane] = v[j];
     const int pidx = lane / LPP;
@@ -194,6 +197,7 @@ __device__ __forceinline__ double sample_sum_finish(double (&t)[K]) {
     double s = tree_sum<K>(t);
     if constexpr (LPP >= 2) s += xchg<1>(s);
     if constexpr (LPP >= 4) s += xchg<2>(s);
+    if constexpr (LPP >= 8) s += xchg<4>(s);
     return s;
 }
 
@@ -303,6 +307,8 @@ __device__ __forceinline__ void apply_cnot(double (&re)[Cfg<N>::R], double (&im)
 }
 
 // entangler ring: for i = 0..N-1 in order CNOT(control=(i+1)%N, target=i); REVERSE undoes it.
+// n <= 6: the whole ring is one lane gather.  n > 6: CNOT_0..CNOT_4 (control and target both on lane bits) are
+// one lane gather per register, the remaining CNOTs touch register bits and are applied one by one.
 template <int N, bool REVERSE>
 __device__ __forceinline__ void apply_ring(double (&re)[Cfg<N>::R], double (&im)[Cfg<N>::R],
                                            int lane, int ring_src_x4) {
@@ -314,22 +320,29 @@ __device__ __forceinline__ void apply_ring(double (&re)[Cfg<N>::R], double (&im)
         re[0] = lane_gather(re[0], ring_src_x4);
         im[0] = lane_gather(im[0], ring_src_x4);
     } else if constexpr (!REVERSE) {
-        static_for<0, N>([&](auto i) { apply_cnot<N, (decltype(i)::value + 1) % N, decltype(i)::value>(re, im, lane); });
+#pragma unroll
+        for (int r = 0; r < C::R; ++r) { re[r] = lane_gather(re[r], ring_src_x4); im[r] = lane_gather(im[r], ring_src_x4); }
+        static_for<C::LB - 1, N>([&](auto i) { apply_cnot<N, (decltype(i)::value + 1) % N, decltype(i)::value>(re, im, lane); });
     } else {
-        static_rfor<0, N>([&](auto i) { apply_cnot<N, (decltype(i)::value + 1) % N, decltype(i)::value>(re, im, lane); });
+        static_rfor<C::LB - 1, N>([&](auto i) { apply_cnot<N, (decltype(i)::value + 1) % N, decltype(i)::value>(re, im, lane); });
+#pragma unroll
+        for (int r = 0; r < C::R; ++r) { re[r] = lane_gather(re[r], ring_src_x4); im[r] = lane_gather(im[r], ring_src_x4); }
     }
 }
 
-// source lane (x4) of the composite ring permutation for the all-lane layout
+// source lane (x4) of the lane-gather part of the ring: all N CNOTs for n <= 6, else CNOT_0..CNOT_{LB-2}
 template <int N>
 __device__ __forceinline__ int ring_source(int lane, bool reverse) {
-    int k = lane & ((1 << N) - 1);
-    if (!reverse) {     // final[k] = old[f0(f1(...f_{N-1}(k)))]
-        for (int i = N - 1; i >= 0; --i) k ^= ((k >> ((i + 1) % N)) & 1) << i;
-    } else {            // inverse: f_{N-1}(...f0(k))
-        for (int i = 0; i < N; ++i) k ^= ((k >> ((i + 1) % N)) & 1) << i;
+    using C = Cfg<N>;
+    constexpr int NC = C::RB == 0 ? N : C::LB - 1;      // CNOTs folded into the gather
+    constexpr int M = C::RB == 0 ? N : C::LB;           // index bits they act on
+    int k = lane & ((1 << M) - 1);
+    if (!reverse) {     // final[k] = old[f0(f1(...f_{NC-1}(k)))]
+        for (int i = NC - 1; i >= 0; --i) k ^= ((k >> ((i + 1) % M)) & 1) << i;
+    } else {            // inverse: f_{NC-1}(...f0(k))
+        for (int i = 0; i < NC; ++i) k ^= ((k >> ((i + 1) % M)) & 1) << i;
     }
-    return ((lane & ~((1 << N) - 1)) | k) << 2;
+    return ((lane & ~((1 << M) - 1)) | k) << 2;
 }
 
 // per-lane partial sums of Im<lam|sigma|psi> for sigma = X,Y,Z on qubit Q
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_kernel(Runs runs, long B, int
     const bool valid = b_raw < B;
     const long b = valid ? b_raw : B - 1;
     const int klow = lane & (C::LANES - 1);
-    const int ring_fwd = ring_source<N < 6 ? N : 6>(lane, false);
+    const int ring_fwd = ring_source<N>(lane, false);
 
     CsStream<N> csx;
     csx.init(cs_lds + wib * kCsPerWave, cs, b, E, lane, lane >> C::LB);
@@ -720,18 +733,18 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
                                                           double* __restrict__ partial) {
     using C = Cfg<N>;
     __shared__ double2 cs_lds[kWaves * kCsPerWave + 16];   // +16: slack for the unclamped prefetch
-    __shared__ double red_lds[C::LDSRED ? kWaves * kRedPerWave : 1];
+    __shared__ double red_lds[C::LDSRED ? kWaves * C::REDW : 1];
     __shared__ __attribute__((aligned(16))) char gate_ring[kWaves * kRingBytesPerWave];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    double* red = red_lds + (C::LDSRED ? wib * kRedPerWave : 0);
+    double* red = red_lds + (C::LDSRED ? wib * C::REDW : 0);
     const long wave = (long)blockIdx.x * kWaves + wib;
     const long b_raw = wave * C::SPW + (lane >> C::LB);
     const bool valid = b_raw < B;
     const long b = valid ? b_raw : B - 1;
     const int klow = lane & (C::LANES - 1);
-    const int ring_fwd = ring_source<N < 6 ? N : 6>(lane, false);
-    const int ring_rev = ring_source<N < 6 ? N : 6>(lane, true);
+    const int ring_fwd = ring_source<N>(lane, false);
+    const int ring_rev = ring_source<N>(lane, true);
 
     CsStream<N> csx;
     csx.init(cs_lds + wib * kCsPerWave, cs, b, E, lane, lane >> C::LB);
