@@ -29,8 +29,11 @@
  * Circuit (core/quantum_circuits_tq.py:79-104): start |0..0>; for each block b:
  *   RX(x[:,col]) on wire j%n for j < enc_per_block[b]; then ld_per_block[b] times
  *   { per wire i: RY(w[s,0,i]) RZ(w[s,1,i]) RY(w[s,2,i]);  for i=0..n-1: CNOT(control=(i+1)%n, target=i) }.
- * Read-out (core/quantum_circuits_tq.py:106-127): H = ham_offset + ham_coeff * sum_i Z_i, or,
+ * Read-out (core/quantum_circuits_tq.py:106-127): H = ham_offset + ham_coeff * sum_i P_i, or,
  *   when ham_diag != NULL, H = diag(ham_diag[k]) with bit i of k = wire i.
+ *   P is the Pauli named by ham_pauli (QHEA_PAULI_Z/X/Y; generate_simple_hamiltonian's `pauli`,
+ *   core/quantum_circuits_ms.py:28-39).  The PyTorch back-ends of the reference only read out Z; X and Y are
+ *   the MindQuantum path's --ham_pauli option.  ham_diag requires QHEA_PAULI_Z.
  *
  * Return value: 0 on success, negative QHEA_E* otherwise (qhea_strerror gives text).
  */
@@ -82,6 +85,10 @@ size_t qhea_workspace_bytes(int n_qubits, int n_blocks,
                             const int32_t* enc_per_block, const int32_t* ld_per_block,
                             int64_t batch);
 
+#define QHEA_PAULI_Z 0
+#define QHEA_PAULI_X 1
+#define QHEA_PAULI_Y 2
+
 /*
  * Forward: out[b] = <psi_b|H|psi_b>.
  * Replaces `_TQHEACircuit.forward` + `_measure` (core/quantum_circuits_tq.py:65-127)
@@ -95,6 +102,7 @@ int qhea_forward(int n_qubits, int n_blocks,
                  int64_t batch,
                  const double* x /*DEVICE [B,E]*/, const double* w /*DEVICE [blk,3,n]*/,
                  double ham_offset, double ham_coeff, const double* ham_diag /*DEVICE [2^n] or NULL*/,
+                 int ham_pauli /*QHEA_PAULI_**/,
                  double* out /*DEVICE [B]*/, double* state_out /*DEVICE [B,2^n,2] or NULL*/,
                  void* workspace /*DEVICE*/, size_t workspace_bytes, void* stream);
 
@@ -111,6 +119,7 @@ int qhea_backward(int n_qubits, int n_blocks,
                   int64_t batch,
                   const double* x /*DEVICE [B,E]*/, const double* w /*DEVICE [blk,3,n]*/,
                   double ham_offset, double ham_coeff, const double* ham_diag /*DEVICE or NULL*/,
+                  int ham_pauli /*QHEA_PAULI_**/,
                   const double* g /*DEVICE [B]*/, const double* state_in /*DEVICE or NULL*/,
                   double* out /*DEVICE [B] or NULL*/,
                   double* grad_x /*DEVICE [B,E]*/, double* grad_w /*DEVICE [blk,3,n]*/,
@@ -147,9 +156,9 @@ typedef struct qhea_model_desc {
     int32_t branch_in;        /* QuanONet: branch input features; HEAQNN: input features             */
     int32_t trunk_in;         /* QuanONet: trunk input features;  HEAQNN: 0                          */
     int32_t trainable_freq;   /* 1: _TiledElementWise (weights+bias in params); 0: _ScaleRepeat      */
-    int32_t reserved;
+    int32_t ham_pauli;        /* QHEA_PAULI_* read-out basis (0 = Z, the reference's default)          */
     double  scale_coeff;      /* fixed scale when trainable_freq == 0                                */
-    double  ham_offset, ham_coeff;   /* H = offset + coeff * sum Z_i (ham_diag is passed per call)   */
+    double  ham_offset, ham_coeff;   /* H = offset + coeff * sum P_i (ham_diag is passed per call)   */
 } qhea_model_desc;
 
 /* Number of trainable scalars for this model (layout above); negative QHEA_E* on a bad descriptor. */

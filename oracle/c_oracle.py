@@ -30,10 +30,10 @@ def lib():
         i32 = ctypes.POINTER(ctypes.c_int32)
         _LIB.qhea_oracle_forward.restype = ctypes.c_int
         _LIB.qhea_oracle_forward.argtypes = [ctypes.c_int, ctypes.c_int, i32, i32, ctypes.c_int64,
-                                             d, d, ctypes.c_double, ctypes.c_double, d, d, d]
+                                             d, d, ctypes.c_double, ctypes.c_double, d, ctypes.c_int, d, d]
         _LIB.qhea_oracle_backward.restype = ctypes.c_int
         _LIB.qhea_oracle_backward.argtypes = [ctypes.c_int, ctypes.c_int, i32, i32, ctypes.c_int64,
-                                              d, d, ctypes.c_double, ctypes.c_double, d, d, d, d, d]
+                                              d, d, ctypes.c_double, ctypes.c_double, d, ctypes.c_int, d, d, d, d]
         _LIB.qhea_oracle_threads.restype = ctypes.c_int
     return _LIB
 
@@ -49,12 +49,16 @@ def _cfg(block_configs):
     return enc, ld, enc.ctypes.data_as(i32), ld.ctypes.data_as(i32)
 
 
+def _pauli(p):
+    return {'Z': 0, 'X': 1, 'Y': 2}[p.upper()] if isinstance(p, str) else int(p)
+
+
 def threads():
     return lib().qhea_oracle_threads()
 
 
 def hea_forward(num_qubits, block_configs, x, w, offset=0.0, coeff=1.0, ham_diag=None,
-                return_state=False):
+                return_state=False, ham_pauli='Z'):
     x = np.ascontiguousarray(x, dtype=np.float64)
     w = np.ascontiguousarray(w, dtype=np.float64)
     diag = None if ham_diag is None else np.ascontiguousarray(ham_diag, dtype=np.float64)
@@ -63,13 +67,13 @@ def hea_forward(num_qubits, block_configs, x, w, offset=0.0, coeff=1.0, ham_diag
     out = np.empty(B)
     st = np.empty((B, 1 << num_qubits, 2)) if return_state else None
     rc = lib().qhea_oracle_forward(num_qubits, len(block_configs), pe, pl, B, _p(x), _p(w),
-                                   float(offset), float(coeff), _p(diag), _p(out), _p(st))
+                                   float(offset), float(coeff), _p(diag), _pauli(ham_pauli), _p(out), _p(st))
     if rc:
         raise ValueError(f"qhea_oracle_forward failed ({rc})")
     return (out, st) if return_state else out
 
 
-def hea_backward(num_qubits, block_configs, x, w, g, offset=0.0, coeff=1.0, ham_diag=None):
+def hea_backward(num_qubits, block_configs, x, w, g, offset=0.0, coeff=1.0, ham_diag=None, ham_pauli='Z'):
     x = np.ascontiguousarray(x, dtype=np.float64)
     w = np.ascontiguousarray(w, dtype=np.float64)
     g = np.ascontiguousarray(g, dtype=np.float64).reshape(-1)
@@ -80,7 +84,7 @@ def hea_backward(num_qubits, block_configs, x, w, g, offset=0.0, coeff=1.0, ham_
     gx = np.zeros_like(x)
     gw = np.zeros_like(w)
     rc = lib().qhea_oracle_backward(num_qubits, len(block_configs), pe, pl, B, _p(x), _p(w),
-                                    float(offset), float(coeff), _p(diag), _p(g),
+                                    float(offset), float(coeff), _p(diag), _pauli(ham_pauli), _p(g),
                                     _p(out), _p(gx), _p(gw))
     if rc:
         raise ValueError(f"qhea_oracle_backward failed ({rc})")

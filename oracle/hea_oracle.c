@@ -105,6 +105,24 @@ static inline double ham_k(long k, int n, double off, double co, const double* d
     return off + co * (double)(n - 2 * __builtin_popcountl((unsigned long)k));
 }
 
+/* hs = H s for H = off + co * sum_q P_q with P = X ('X') or Y ('Y'), written out Pauli by Pauli
+ * (generate_simple_hamiltonian's `pauli`, core/quantum_circuits_ms.py:28-39).  Deliberately NOT the
+ * basis-change trick the HIP kernels use, so the two stay independent statements. */
+static void apply_pauli_ham(const cplx* s, cplx* hs, int n, double off, double co, int pauli) {
+    const long dim = 1L << n;
+    for (long k = 0; k < dim; ++k) {
+        double re = off * s[k].re, im = off * s[k].im;
+        for (int q = 0; q < n; ++q) {
+            const long m = 1L << q;
+            const cplx p = s[k ^ m];
+            if (pauli == 1) { re += co * p.re; im += co * p.im; }
+            else if (k & m) { re += co * -p.im; im += co * p.re; }     /* (sigma_y psi)_1 = +i psi_0 */
+            else            { re += co * p.im;  im += co * -p.re; }    /* (sigma_y psi)_0 = -i psi_1 */
+        }
+        hs[k].re = re; hs[k].im = im;
+    }
+}
+
 static int check(int n, int nb, const int32_t* enc, const int32_t* ld, long* E, long* blk) {
     if (n < 2 || n > MAXQ || nb < 0 || (nb > 0 && (!enc || !ld))) return -1;
     *E = 0; *blk = 0;
@@ -117,34 +135,42 @@ static int check(int n, int nb, const int32_t* enc, const int32_t* ld, long* E, 
 
 int qhea_oracle_forward(int n, int nb, const int32_t* enc, const int32_t* ld, int64_t B,
                         const double* x, const double* w, double off, double co,
-                        const double* diag, double* out, double* state_out) {
+                        const double* diag, int pauli, double* out, double* state_out) {
     long E, blk;
     if (check(n, nb, enc, ld, &E, &blk) || B < 0 || !out || (B > 0 && E > 0 && !x) || (blk > 0 && !w))
         return -1;
+    if (pauli < 0 || pauli > 2 || (pauli && diag)) return -1;
     const long dim = 1L << n;
 #pragma omp parallel
     {
         cplx* s = (cplx*)malloc(sizeof(cplx) * dim);
+        cplx* hs = (cplx*)malloc(sizeof(cplx) * dim);
 #pragma omp for schedule(static)
         for (int64_t b = 0; b < B; ++b) {
             run_forward(s, n, nb, enc, ld, x + b * E, w);
             double acc = 0.0;
-            for (long k = 0; k < dim; ++k)
-                acc += ham_k(k, n, off, co, diag) * (s[k].re * s[k].re + s[k].im * s[k].im);
+            if (pauli == 0) {
+                for (long k = 0; k < dim; ++k)
+                    acc += ham_k(k, n, off, co, diag) * (s[k].re * s[k].re + s[k].im * s[k].im);
+            } else {
+                apply_pauli_ham(s, hs, n, off, co, pauli);
+                for (long k = 0; k < dim; ++k) acc += s[k].re * hs[k].re + s[k].im * hs[k].im;
+            }
             out[b] = acc;
             if (state_out) memcpy(state_out + b * dim * 2, s, sizeof(cplx) * dim);
         }
-        free(s);
+        free(s); free(hs);
     }
     return 0;
 }
 
 int qhea_oracle_backward(int n, int nb, const int32_t* enc, const int32_t* ld, int64_t B,
                          const double* x, const double* w, double off, double co,
-                         const double* diag, const double* g,
+                         const double* diag, int pauli, const double* g,
                          double* out, double* grad_x, double* grad_w) {
     long E, blk;
     if (check(n, nb, enc, ld, &E, &blk) || B < 0 || !g || !grad_x || !grad_w) return -1;
+    if (pauli < 0 || pauli > 2 || (pauli && diag)) return -1;
     const long dim = 1L << n, P = blk * 3 * n;
     int nthreads = 1;
 #ifdef _OPENMP
@@ -167,11 +193,19 @@ int qhea_oracle_backward(int n, int nb, const int32_t* enc, const int32_t* ld, i
             double* gxb = grad_x + b * E;
             run_forward(s, n, nb, enc, ld, xb, w);
             double acc = 0.0;
-            for (long k = 0; k < dim; ++k) {
-                const double h = ham_k(k, n, off, co, diag);
-                acc += h * (s[k].re * s[k].re + s[k].im * s[k].im);
-                lam[k].re = g[b] * h * s[k].re;
-                lam[k].im = g[b] * h * s[k].im;
+            if (pauli == 0) {
+                for (long k = 0; k < dim; ++k) {
+                    const double h = ham_k(k, n, off, co, diag);
+                    acc += h * (s[k].re * s[k].re + s[k].im * s[k].im);
+                    lam[k].re = g[b] * h * s[k].re;
+                    lam[k].im = g[b] * h * s[k].im;
+                }
+            } else {
+                apply_pauli_ham(s, lam, n, off, co, pauli);
+                for (long k = 0; k < dim; ++k) {
+                    acc += s[k].re * lam[k].re + s[k].im * lam[k].im;
+                    lam[k].re *= g[b]; lam[k].im *= g[b];
+                }
             }
             if (out) out[b] = acc;
             long col = E, sub = blk;

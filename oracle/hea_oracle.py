@@ -168,14 +168,43 @@ def hea_state(num_qubits, block_configs, x, w):
     return psi
 
 
-def hea_forward(num_qubits, block_configs, x, w, offset=0.0, coeff=1.0, ham_diag=None):
+def _apply_pauli_ham(psi, n, offset, coeff, pauli):
+    """H psi for H = offset + coeff * sum_q P_q, P = 'X' or 'Y', Pauli by Pauli
+    (generate_simple_hamiltonian's `pauli`, core/quantum_circuits_ms.py:28-39)."""
+    out = offset * psi
+    for q in range(n):
+        i0, i1 = _pairs(n, q)
+        sp = np.empty_like(psi)
+        if pauli == 'X':
+            sp[:, i0] = psi[:, i1]
+            sp[:, i1] = psi[:, i0]
+        else:
+            sp[:, i0] = -1j * psi[:, i1]
+            sp[:, i1] = 1j * psi[:, i0]
+        out = out + coeff * sp
+    return out
+
+
+def _check_pauli(ham_pauli, ham_diag):
+    p = str(ham_pauli).upper()
+    if p not in ('X', 'Y', 'Z'):
+        raise ValueError(f"ham_pauli must be X, Y or Z, got {ham_pauli!r}")
+    if p != 'Z' and ham_diag is not None:
+        raise ValueError("ham_diag is a Z-basis diagonal; it excludes ham_pauli X/Y (utils/common.py:84)")
+    return p
+
+
+def hea_forward(num_qubits, block_configs, x, w, offset=0.0, coeff=1.0, ham_diag=None, ham_pauli='Z'):
     """out[B] = <psi|H|psi>   (no bias)."""
+    pauli = _check_pauli(ham_pauli, ham_diag)
     psi = hea_state(num_qubits, block_configs, x, w)
+    if pauli != 'Z':
+        return np.real(np.sum(np.conj(psi) * _apply_pauli_ham(psi, num_qubits, offset, coeff, pauli), axis=1))
     H = ham_diagonal(num_qubits, offset, coeff, ham_diag)
     return np.sum((psi.real ** 2 + psi.imag ** 2) * H[None, :], axis=1)
 
 
-def hea_backward(num_qubits, block_configs, x, w, g, offset=0.0, coeff=1.0, ham_diag=None):
+def hea_backward(num_qubits, block_configs, x, w, g, offset=0.0, coeff=1.0, ham_diag=None, ham_pauli='Z'):
     """
     Adjoint differentiation (the scheme MindQuantum's
     get_expectation_with_grad uses, core/quantum_circuits_ms.py:229-233).
@@ -188,10 +217,16 @@ def hea_backward(num_qubits, block_configs, x, w, g, offset=0.0, coeff=1.0, ham_
     w = np.asarray(w, dtype=np.float64)
     g = np.asarray(g, dtype=np.float64).reshape(-1)
     B, E = x.shape
+    pauli = _check_pauli(ham_pauli, ham_diag)
     psi = hea_state(n, block_configs, x, w)
-    H = ham_diagonal(n, offset, coeff, ham_diag)
-    out = np.sum((psi.real ** 2 + psi.imag ** 2) * H[None, :], axis=1)
-    lam = psi * H[None, :] * g[:, None]          # upstream weight folded into lambda
+    if pauli != 'Z':
+        hpsi = _apply_pauli_ham(psi, n, offset, coeff, pauli)
+        out = np.real(np.sum(np.conj(psi) * hpsi, axis=1))
+        lam = hpsi * g[:, None]
+    else:
+        H = ham_diagonal(n, offset, coeff, ham_diag)
+        out = np.sum((psi.real ** 2 + psi.imag ** 2) * H[None, :], axis=1)
+        lam = psi * H[None, :] * g[:, None]          # upstream weight folded into lambda
     grad_x = np.zeros((B, E))
     grad_w = np.zeros_like(w)
 
@@ -254,7 +289,7 @@ def scale_repeat(x, scale, out_features):
 
 
 def quanonet_forward(params, branch, trunk, num_qubits, net_size, ham_bound=(-5.0, 5.0),
-                     ham_diag=None):
+                     ham_diag=None, ham_pauli='Z'):
     """
     QuanONetPT.forward (models_pt.py:153-166), trainable-frequency form.
     params: dict with the PT state_dict keys (branch_freq.weights, ...).
@@ -265,12 +300,12 @@ def quanonet_forward(params, branch, trunk, num_qubits, net_size, ham_bound=(-5.
     x = np.concatenate([t_enc, b_enc], axis=1)            # trunk first
     off, co = ham_params(num_qubits, *ham_bound)
     cfgs = block_configs_quanonet(num_qubits, net_size)
-    out = hea_forward(num_qubits, cfgs, x, params['quantum_layer.ansatz_weights'], off, co, ham_diag)
+    out = hea_forward(num_qubits, cfgs, x, params['quantum_layer.ansatz_weights'], off, co, ham_diag, ham_pauli)
     return out + float(np.asarray(params['bias']).reshape(-1)[0])
 
 
 def quanonet_loss_and_grads(params, branch, trunk, y, num_qubits, net_size,
-                            ham_bound=(-5.0, 5.0), batch_total=None):
+                            ham_bound=(-5.0, 5.0), batch_total=None, ham_pauli='Z'):
     """
     MSE(mean) loss and gradients w.r.t. every QuanONetPT parameter, restating what
     torch autograd produces for solver_pt.py:232-236.  ``batch_total`` is the global
@@ -292,10 +327,10 @@ def quanonet_loss_and_grads(params, branch, trunk, y, num_qubits, net_size,
     cfgs = block_configs_quanonet(num_qubits, net_size)
     w = params['quantum_layer.ansatz_weights']
     bias = float(np.asarray(params['bias']).reshape(-1)[0])
-    out = hea_forward(num_qubits, cfgs, x, w, off, co) + bias
+    out = hea_forward(num_qubits, cfgs, x, w, off, co, ham_pauli=ham_pauli) + bias
     resid = out - y
     g = 2.0 * resid / Bt
-    _, gx, gw = hea_backward(num_qubits, cfgs, x, w, g, off, co)
+    _, gx, gw = hea_backward(num_qubits, cfgs, x, w, g, off, co, ham_pauli=ham_pauli)
     nt = tw.shape[0]
     grads = {
         'trunk_freq.weights': np.sum(gx[:, :nt] * t_til, axis=0),
@@ -312,14 +347,14 @@ def quanonet_loss_and_grads(params, branch, trunk, y, num_qubits, net_size,
 # --------------------------------------------------------------------------
 # self-checks that need no external oracle
 # --------------------------------------------------------------------------
-def param_shift_grad_w(num_qubits, block_configs, x, w, g, offset, coeff, idx):
+def param_shift_grad_w(num_qubits, block_configs, x, w, g, offset, coeff, idx, ham_pauli='Z'):
     """Exact derivative of sum_b g_b out_b w.r.t. w[idx] by the parameter-shift rule."""
     wp = np.array(w, dtype=np.float64)
     wm = np.array(w, dtype=np.float64)
     wp[idx] += np.pi / 2
     wm[idx] -= np.pi / 2
-    fp = hea_forward(num_qubits, block_configs, x, wp, offset, coeff)
-    fm = hea_forward(num_qubits, block_configs, x, wm, offset, coeff)
+    fp = hea_forward(num_qubits, block_configs, x, wp, offset, coeff, ham_pauli=ham_pauli)
+    fm = hea_forward(num_qubits, block_configs, x, wm, offset, coeff, ham_pauli=ham_pauli)
     return float(np.sum(np.asarray(g) * 0.5 * (fp - fm)))
 
 

@@ -22,11 +22,24 @@ class ModelDesc(ctypes.Structure):
     """Mirror of `qhea_model_desc` (include/quanonet_hea.h)."""
     _fields_ = [('model', ctypes.c_int32), ('n_qubits', ctypes.c_int32), ('net', ctypes.c_int32 * 4),
                 ('branch_in', ctypes.c_int32), ('trunk_in', ctypes.c_int32),
-                ('trainable_freq', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('trainable_freq', ctypes.c_int32), ('ham_pauli', ctypes.c_int32),
                 ('scale_coeff', ctypes.c_double), ('ham_offset', ctypes.c_double), ('ham_coeff', ctypes.c_double)]
 
 
 MODEL_QUANONET, MODEL_HEAQNN = 0, 1
+MIN_LIB_VERSION = 200           # 0.2.0: qhea_forward/backward take ham_pauli
+PAULI = {'Z': 0, 'X': 1, 'Y': 2}
+
+
+def pauli_code(p):
+    """'Z'/'X'/'Y' (the reference's --ham_pauli choices, utils/common.py:81) or 0/1/2 -> QHEA_PAULI_*."""
+    if isinstance(p, str):
+        if p.upper() not in PAULI:
+            raise ValueError(f"ham_pauli must be one of X, Y, Z (got {p!r})")
+        return PAULI[p.upper()]
+    if int(p) not in (0, 1, 2):
+        raise ValueError(f"ham_pauli code must be 0, 1 or 2 (got {p!r})")
+    return int(p)
 
 _lib = None
 
@@ -44,6 +57,10 @@ def load():
         raise QheaError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                         f"g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    lib.qhea_version.restype = ctypes.c_int
+    if lib.qhea_version() < MIN_LIB_VERSION:
+        raise QheaError(f"{LIB_PATH} is version {lib.qhea_version()}, this binding needs >= {MIN_LIB_VERSION} "
+                        f"(the ham_pauli argument changed the qhea_forward/backward signatures): rebuild it")
     vp, dp = ctypes.c_void_p, ctypes.c_void_p
     i32p = ctypes.POINTER(ctypes.c_int32)
     lib.qhea_version.restype = ctypes.c_int
@@ -54,10 +71,10 @@ def load():
     lib.qhea_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, i32p, i32p, ctypes.c_int64]
     lib.qhea_forward.restype = ctypes.c_int
     lib.qhea_forward.argtypes = [ctypes.c_int, ctypes.c_int, i32p, i32p, ctypes.c_int64, dp, dp,
-                                 ctypes.c_double, ctypes.c_double, dp, dp, dp, vp, ctypes.c_size_t, vp]
+                                 ctypes.c_double, ctypes.c_double, dp, ctypes.c_int, dp, dp, vp, ctypes.c_size_t, vp]
     lib.qhea_backward.restype = ctypes.c_int
     lib.qhea_backward.argtypes = [ctypes.c_int, ctypes.c_int, i32p, i32p, ctypes.c_int64, dp, dp,
-                                  ctypes.c_double, ctypes.c_double, dp, dp, dp, dp, dp, dp,
+                                  ctypes.c_double, ctypes.c_double, dp, ctypes.c_int, dp, dp, dp, dp, dp,
                                   vp, ctypes.c_size_t, vp]
     lib.qhea_profile_next_circuit_kernel.restype = ctypes.c_int
     lib.qhea_profile_next_circuit_kernel.argtypes = [vp, vp]
@@ -133,7 +150,7 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def hea_forward(shape, x, w, ham_offset, ham_coeff, ham_diag=None, return_state=False):
+def hea_forward(shape, x, w, ham_offset, ham_coeff, ham_diag=None, return_state=False, ham_pauli=0):
     """out[B] (and optionally the final state [B,2^n,2]) on x.device.  No bias."""
     lib = load()
     B = x.shape[0]
@@ -146,13 +163,14 @@ def hea_forward(shape, x, w, ham_offset, ham_coeff, ham_diag=None, return_state=
     ws = _workspace(x.device, nbytes)
     with torch.cuda.device(x.device):
         rc = lib.qhea_forward(shape.n, shape.nb, shape._enc, shape._ld, B, _ptr(x), _ptr(w),
-                              float(ham_offset), float(ham_coeff), _ptr(ham_diag), _ptr(out), _ptr(state),
+                              float(ham_offset), float(ham_coeff), _ptr(ham_diag), pauli_code(ham_pauli),
+                              _ptr(out), _ptr(state),
                               _ptr(ws), ws.numel(), _stream(x.device))
     _check(rc, 'qhea_forward')
     return (out, state) if return_state else out
 
 
-def hea_backward(shape, x, w, g, ham_offset, ham_coeff, ham_diag=None, state=None, want_out=False):
+def hea_backward(shape, x, w, g, ham_offset, ham_coeff, ham_diag=None, state=None, want_out=False, ham_pauli=0):
     """(grad_x[B,E], grad_w[blk,3,n][, out[B]]) for upstream g[B]."""
     lib = load()
     B = x.shape[0]
@@ -168,7 +186,8 @@ def hea_backward(shape, x, w, g, ham_offset, ham_coeff, ham_diag=None, state=Non
     ws = _workspace(x.device, nbytes)
     with torch.cuda.device(x.device):
         rc = lib.qhea_backward(shape.n, shape.nb, shape._enc, shape._ld, B, _ptr(x), _ptr(w),
-                               float(ham_offset), float(ham_coeff), _ptr(ham_diag), _ptr(g), _ptr(state),
+                               float(ham_offset), float(ham_coeff), _ptr(ham_diag), pauli_code(ham_pauli),
+                               _ptr(g), _ptr(state),
                                _ptr(out), _ptr(grad_x), _ptr(grad_w), _ptr(ws), ws.numel(),
                                _stream(x.device))
     _check(rc, 'qhea_backward')
@@ -179,10 +198,10 @@ def hea_backward(shape, x, w, g, ham_offset, ham_coeff, ham_diag=None, state=Non
 # model-level (fused) calls
 # ---------------------------------------------------------------------------------------------------
 def make_model_desc(model, n_qubits, net_size, branch_in, trunk_in, trainable_freq, scale_coeff,
-                    ham_offset, ham_coeff):
+                    ham_offset, ham_coeff, ham_pauli=0):
     net = list(net_size) + [0] * (4 - len(net_size))
     d = ModelDesc(int(model), int(n_qubits), (ctypes.c_int32 * 4)(*[int(v) for v in net[:4]]), int(branch_in),
-                  int(trunk_in), 1 if trainable_freq else 0, 0, float(scale_coeff), float(ham_offset),
+                  int(trunk_in), 1 if trainable_freq else 0, pauli_code(ham_pauli), float(scale_coeff), float(ham_offset),
                   float(ham_coeff))
     return d
 

@@ -35,29 +35,31 @@ class _HEAFunction(torch.autograd.Function):
     """out[B] = <psi(x,w)|H|psi(x,w)>; backward = in-kernel adjoint differentiation."""
 
     @staticmethod
-    def forward(ctx, x, w, shape, ham_offset, ham_coeff, ham_diag):
+    def forward(ctx, x, w, shape, ham_offset, ham_coeff, ham_diag, ham_pauli=0):
         x64 = x.detach().to(torch.float64).contiguous()
         w64 = w.detach().to(torch.float64).contiguous()
         d64 = None if ham_diag is None else ham_diag.detach().to(torch.float64).contiguous()
         need_grad = x.requires_grad or w.requires_grad
         if need_grad:
-            out, state = _lib.hea_forward(shape, x64, w64, ham_offset, ham_coeff, d64, return_state=True)
+            out, state = _lib.hea_forward(shape, x64, w64, ham_offset, ham_coeff, d64, return_state=True,
+                                          ham_pauli=ham_pauli)
             ctx.save_for_backward(x64, w64, state, d64 if d64 is not None else x64.new_empty(0))
         else:
-            out = _lib.hea_forward(shape, x64, w64, ham_offset, ham_coeff, d64)
+            out = _lib.hea_forward(shape, x64, w64, ham_offset, ham_coeff, d64, ham_pauli=ham_pauli)
         ctx.shape = shape
-        ctx.ham = (ham_offset, ham_coeff, d64 is not None)
+        ctx.ham = (ham_offset, ham_coeff, d64 is not None, ham_pauli)
         ctx.dtypes = (x.dtype, w.dtype)
         return out.to(torch.promote_types(x.dtype, w.dtype))
 
     @staticmethod
     def backward(ctx, grad_out):
         x64, w64, state, d64 = ctx.saved_tensors
-        off, co, has_diag = ctx.ham
+        off, co, has_diag, pauli = ctx.ham
         g = grad_out.detach().to(torch.float64).contiguous()
-        gx, gw = _lib.hea_backward(ctx.shape, x64, w64, g, off, co, d64 if has_diag else None, state=state)
+        gx, gw = _lib.hea_backward(ctx.shape, x64, w64, g, off, co, d64 if has_diag else None, state=state,
+                                   ham_pauli=pauli)
         xd, wd = ctx.dtypes
-        return gx.to(xd), gw.to(wd), None, None, None, None
+        return gx.to(xd), gw.to(wd), None, None, None, None, None
 
 
 class HEACircuitHIP(nn.Module):
@@ -69,7 +71,7 @@ class HEACircuitHIP(nn.Module):
     """
 
     def __init__(self, n_wires, block_configs, ham_offset=0.0, ham_coeff_per_qubit=0.0, ham_diag=None,
-                 dtype=torch.float64):
+                 dtype=torch.float64, ham_pauli='Z'):
         super().__init__()
         if n_wires < 2:
             # MindQuantum skips the entangler for n=1 (quantum_circuits_ms.py:140) while TorchQuantum
@@ -83,6 +85,11 @@ class HEACircuitHIP(nn.Module):
         w32 = torch.empty(total_ansatz_blocks, 3, self.n_wires)          # float32 draw == reference draw
         nn.init.uniform_(w32, -np.pi, np.pi)
         self.ansatz_weights = nn.Parameter(w32.to(dtype))
+        # read-out Pauli of the simple Hamiltonian (generate_simple_hamiltonian's `pauli`,
+        # core/quantum_circuits_ms.py:28-39; the reference's PT back-ends only have Z)
+        self.ham_pauli = _lib.pauli_code(ham_pauli)
+        if ham_diag is not None and self.ham_pauli != 0:
+            raise ValueError("ham_diag is a Z-basis diagonal: it overrides ham_pauli (utils/common.py:84); pass 'Z'")
         if ham_diag is not None:
             self.register_buffer('ham_diag', torch.as_tensor(np.asarray(ham_diag), dtype=dtype).reshape(-1))
             if self.ham_diag.numel() != 1 << self.n_wires:
@@ -103,26 +110,29 @@ class HEACircuitHIP(nn.Module):
         if x.dim() != 2 or x.shape[1] != self._shape.E:
             raise ValueError(f"expected x of shape (batch, {self._shape.E}), got {tuple(x.shape)}")
         diag = self.ham_diag if self.use_full_ham else None
-        out = _HEAFunction.apply(x, self.ansatz_weights, self._shape, self.ham_offset, self.ham_coeff, diag)
+        out = _HEAFunction.apply(x, self.ansatz_weights, self._shape, self.ham_offset, self.ham_coeff, diag,
+                                 self.ham_pauli)
         return out.unsqueeze(-1)
 
 
 def build_quanonet_hip(num_qubits, branch_input_size, trunk_input_size, net_size,
-                       ham_bound=(-5.0, 5.0), ham_diag=None, dtype=torch.float64):
+                       ham_bound=(-5.0, 5.0), ham_diag=None, dtype=torch.float64, ham_pauli='Z'):
     """Mirror of build_quanonet_tq (core/quantum_circuits_tq.py:149-176)."""
     bd, bl, td, tl = net_size
     cfgs = _make_block_configs(num_qubits, td, tl, bd, bl)
     if ham_diag is not None:
         return HEACircuitHIP(num_qubits, cfgs, ham_diag=ham_diag, dtype=dtype)
     off, co = _ham_params(num_qubits, ham_bound[0], ham_bound[1])
-    return HEACircuitHIP(num_qubits, cfgs, ham_offset=off, ham_coeff_per_qubit=co, dtype=dtype)
+    return HEACircuitHIP(num_qubits, cfgs, ham_offset=off, ham_coeff_per_qubit=co, dtype=dtype,
+                         ham_pauli=ham_pauli)
 
 
 def build_heaqnn_hip(num_qubits, input_size, net_size, ham_bound=(-5.0, 5.0), ham_diag=None,
-                     dtype=torch.float64):
+                     dtype=torch.float64, ham_pauli='Z'):
     """Mirror of build_heaqnn_tq (core/quantum_circuits_tq.py:179-202)."""
     cfgs = [(num_qubits, net_size[1])] * net_size[0]
     if ham_diag is not None:
         return HEACircuitHIP(num_qubits, cfgs, ham_diag=ham_diag, dtype=dtype)
     off, co = _ham_params(num_qubits, ham_bound[0], ham_bound[1])
-    return HEACircuitHIP(num_qubits, cfgs, ham_offset=off, ham_coeff_per_qubit=co, dtype=dtype)
+    return HEACircuitHIP(num_qubits, cfgs, ham_offset=off, ham_coeff_per_qubit=co, dtype=dtype,
+                         ham_pauli=ham_pauli)

@@ -365,8 +365,13 @@ struct ModelInfo {
     long P = 0, off_ans = 0, off_bias = -1, off_w[2] = {-1, -1}, off_b[2] = {-1, -1};
 };
 
+inline bool pauli_ok(int pauli, const double* ham_diag) {       // a diagonal Hamiltonian is a Z-basis object
+    return pauli == QHEA_PAULI_Z || ((pauli == QHEA_PAULI_X || pauli == QHEA_PAULI_Y) && !ham_diag);
+}
+
 int model_info(const qhea_model_desc* d, ModelInfo& mi) {
     if (!d) return QHEA_EINVAL;
+    if (d->ham_pauli < QHEA_PAULI_Z || d->ham_pauli > QHEA_PAULI_Y) return QHEA_EINVAL;
     const int n = d->n_qubits;
     if (n < QHEA_MIN_QUBITS || n > QHEA_MAX_QUBITS) return QHEA_EINVAL;
     for (int i = 0; i < 4; ++i) if (d->net[i] < 0) return QHEA_EINVAL;
@@ -459,7 +464,7 @@ using namespace qhea;
 
 extern "C" {
 
-int qhea_version(void) { return 100; }
+int qhea_version(void) { return 200; }
 
 const char* qhea_strerror(int code) {
     switch (code) {
@@ -494,12 +499,12 @@ size_t qhea_workspace_bytes(int n_qubits, int n_blocks, const int32_t* enc_per_b
 
 int qhea_forward(int n_qubits, int n_blocks, const int32_t* enc_per_block, const int32_t* ld_per_block,
                  int64_t batch, const double* x, const double* w, double ham_offset, double ham_coeff,
-                 const double* ham_diag, double* out, double* state_out, void* workspace,
+                 const double* ham_diag, int ham_pauli, double* out, double* state_out, void* workspace,
                  size_t workspace_bytes, void* stream) {
     Shape sh;
     int rc = make_shape(n_qubits, n_blocks, enc_per_block, ld_per_block, sh);
     if (rc != QHEA_OK) return rc;
-    if (batch < 0) return QHEA_EINVAL;
+    if (batch < 0 || !pauli_ok(ham_pauli, ham_diag)) return QHEA_EINVAL;
     if (batch == 0) return QHEA_OK;
     if (!out || (sh.E > 0 && !x) || (sh.blk > 0 && !w)) return QHEA_EINVAL;
     const Layout L = make_layout(n_qubits, sh, batch);
@@ -513,7 +518,7 @@ int qhea_forward(int n_qubits, int n_blocks, const int32_t* enc_per_block, const
     const char* gates = ws + L.off_U;
     const int gates_bytes = (int)((sh.blk + 2) * n_qubits * kGateBytes);
     const FwdArgs fa{sh.runs, (long)batch, (int)sh.E, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, out,
-                     state_out, nullptr};
+                     state_out, nullptr, ham_pauli};
     profile_begin(st);
     if (L.lds_fwd) {
         if (launch_lds_fwd(n_qubits, (long)batch, st, fa) != QHEA_OK) return QHEA_ELAUNCH;
@@ -529,12 +534,12 @@ int qhea_forward(int n_qubits, int n_blocks, const int32_t* enc_per_block, const
 
 int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, const int32_t* ld_per_block,
                   int64_t batch, const double* x, const double* w, double ham_offset, double ham_coeff,
-                  const double* ham_diag, const double* g, const double* state_in, double* out,
+                  const double* ham_diag, int ham_pauli, const double* g, const double* state_in, double* out,
                   double* grad_x, double* grad_w, void* workspace, size_t workspace_bytes, void* stream) {
     Shape sh;
     int rc = make_shape(n_qubits, n_blocks, enc_per_block, ld_per_block, sh);
     if (rc != QHEA_OK) return rc;
-    if (batch < 0) return QHEA_EINVAL;
+    if (batch < 0 || !pauli_ok(ham_pauli, ham_diag)) return QHEA_EINVAL;
     if ((sh.blk > 0 && (!w || !grad_w))) return QHEA_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (batch == 0) {
@@ -554,7 +559,7 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
     const int gates_bytes = (int)((sh.blk + 2) * n_qubits * kGateBytes);
     double* partial = reinterpret_cast<double*>(ws + L.off_part);
     const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, g,
-                     state_in, nullptr, nullptr, 0.0, out, grad_x, partial};
+                     state_in, nullptr, nullptr, 0.0, out, grad_x, partial, ham_pauli};
     profile_begin(st);
     if (L.lds_bwd) {
         if (launch_lds_bwd(n_qubits, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;
@@ -592,7 +597,7 @@ int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double*
     ModelInfo mi;
     int rc = model_info(desc, mi);
     if (rc != QHEA_OK) return rc;
-    if (batch < 0) return QHEA_EINVAL;
+    if (batch < 0 || !pauli_ok(desc->ham_pauli, ham_diag)) return QHEA_EINVAL;
     if (batch == 0) return QHEA_OK;
     if (!branch || !params || !pred || (desc->model == QHEA_MODEL_QUANONET && !trunk)) return QHEA_EINVAL;
     const ModelLayout M = make_model_layout(mi, batch);
@@ -605,7 +610,7 @@ int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double*
     const dim3 grid((unsigned)(M.L.nwaves_fwd / kWaves));
     const FwdArgs fa{mi.sh.runs, (long)batch, (int)mi.sh.E, reinterpret_cast<const double2*>(ws + M.L.off_cs),
                      ws + M.L.off_U, (int)((mi.sh.blk + 2) * mi.n * kGateBytes), desc->ham_offset, desc->ham_coeff,
-                     ham_diag, pred, nullptr, mi.has_bias ? params + mi.off_bias : nullptr};
+                     ham_diag, pred, nullptr, mi.has_bias ? params + mi.off_bias : nullptr, desc->ham_pauli};
     profile_begin(st);
     if (M.L.lds_fwd) {
         if (launch_lds_fwd(mi.n, (long)batch, st, fa) != QHEA_OK) return QHEA_ELAUNCH;
@@ -625,7 +630,7 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const doubl
     ModelInfo mi;
     int rc = model_info(desc, mi);
     if (rc != QHEA_OK) return rc;
-    if (batch < 0 || !grad) return QHEA_EINVAL;
+    if (batch < 0 || !grad || !pauli_ok(desc->ham_pauli, ham_diag)) return QHEA_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (batch == 0) {
         return hipMemsetAsync(grad, 0, sizeof(double) * (mi.P + 2), st) == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
@@ -645,7 +650,7 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const doubl
                      reinterpret_cast<const double2*>(ws + M.L.off_cs), ws + M.L.off_U,
                      (int)((mi.sh.blk + 2) * mi.n * kGateBytes), desc->ham_offset, desc->ham_coeff, ham_diag,
                      nullptr, nullptr, y, mi.has_bias ? params + mi.off_bias : nullptr, inv_batch_total,
-                     pr, gx, partial};
+                     pr, gx, partial, desc->ham_pauli};
     profile_begin(st);
     if (M.L.lds_bwd) {
         if (launch_lds_bwd(mi.n, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;

@@ -408,6 +408,25 @@ __device__ __forceinline__ double ham_weight(int k, double off, double co, const
     return off + co * (double)(N - 2 * (int)__popc((unsigned)k));
 }
 
+// Readout in another Pauli basis (reference ham_pauli, core/quantum_circuits_ms.py:28-39): sum_i <P_i> is the
+// Z readout of V psi with V = RY(-pi/2) on every qubit for P = X and RX(+pi/2) for P = Y.  DAGGER undoes it.
+// pauli: 0 = Z (nothing to do), 1 = X, 2 = Y.
+template <int N, bool DAGGER>
+__device__ __forceinline__ void basis_change(double (&re)[Cfg<N>::R], double (&im)[Cfg<N>::R], int pauli, int lane) {
+    using C = Cfg<N>;
+    constexpr double kR = 0.70710678118654752440;
+    if (pauli == 1) {
+        static_for<0, N>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            double sbr = DAGGER ? -kR : kR;
+            if constexpr (Q < C::LB) sbr = ((lane >> Q) & 1) ? -sbr : sbr;
+            apply_su2<N, Q>(re, im, kR, 0.0, sbr, 0.0);
+        });
+    } else if (pauli == 2) {
+        static_for<0, N>([&](auto q) { apply_rx<N, decltype(q)::value>(re, im, kR, DAGGER ? -kR : kR); });
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // operand streams: gate coefficients (global, per-lane variant, rolling prefetch) and
 // per-sample RX (cos,sin) pairs (wave-private LDS window + one-block register prefetch)
@@ -678,7 +697,7 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_kernel(Runs runs, long B, int
                                                           const double2* __restrict__ cs,
                                                           const char* __restrict__ gates, int gates_bytes,
                                                           double off, double co,
-                                                          const double* __restrict__ diag,
+                                                          const double* __restrict__ diag, int pauli,
                                                           double* __restrict__ out,
                                                           double* __restrict__ state_out,
                                                           const double* __restrict__ bias) {
@@ -702,16 +721,18 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_kernel(Runs runs, long B, int
     double re[C::R], im[C::R];
     forward_sweep<N>(re, im, runs, csx, gs, lane, ring_fwd);
 
-    double acc = 0.0;
+    if (state_out && valid) {                                  // psi_N, before any readout-basis change
 #pragma unroll
-    for (int r = 0; r < C::R; ++r) {
-        const int k = (r << C::LB) | klow;
-        acc += ham_weight<N>(k, off, co, diag) * (re[r] * re[r] + im[r] * im[r]);
-        if (state_out && valid) {
-            double2* dst = reinterpret_cast<double2*>(state_out) + (b << N) + k;
+        for (int r = 0; r < C::R; ++r) {
+            double2* dst = reinterpret_cast<double2*>(state_out) + (b << N) + ((r << C::LB) | klow);
             *dst = make_double2(re[r], im[r]);
         }
     }
+    basis_change<N, false>(re, im, pauli, lane);
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < C::R; ++r)
+        acc += ham_weight<N>((r << C::LB) | klow, off, co, diag) * (re[r] * re[r] + im[r] * im[r]);
     double v[1] = {acc};
     lane_reduce<1, C::LB>(v, lane);
     if (valid && klow == 0) out[b] = v[0] + (bias ? bias[0] : 0.0);
@@ -722,7 +743,7 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
                                                           const double2* __restrict__ cs,
                                                           const char* __restrict__ gates, int gates_bytes,
                                                           double off, double co,
-                                                          const double* __restrict__ diag,
+                                                          const double* __restrict__ diag, int pauli,
                                                           const double* __restrict__ g,
                                                           const double* __restrict__ state_in,
                                                           const double* __restrict__ y,
@@ -762,6 +783,7 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
         forward_sweep<N>(pr, pi, runs, csx, gs, lane, ring_fwd);
     }
 
+    basis_change<N, false>(pr, pi, pauli, lane);
     // upstream weight: given (g), or the fused MSE residual 2 (out + bias - y) / batch_total when y != NULL
     double acc = 0.0;
 #pragma unroll
@@ -783,6 +805,10 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
         const double h = ham_weight<N>((r << C::LB) | klow, off, co, diag);
         lr[r] = gb * h * pr[r];
         li[r] = gb * h * pi[r];
+    }
+    if (pauli) {
+        basis_change<N, true>(pr, pi, pauli, lane);
+        basis_change<N, true>(lr, li, pauli, lane);
     }
 
     double* __restrict__ part_w = partial + wave * (long)blk * C::KW;
@@ -907,7 +933,7 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
                                                        const double2* __restrict__ cs,
                                                        const char* __restrict__ gates, int gates_bytes,
                                                        double off, double co,
-                                                       const double* __restrict__ diag,
+                                                       const double* __restrict__ diag, int pauli,
                                                        const double* __restrict__ g,
                                                        const double* __restrict__ state_in,
                                                        const double* __restrict__ y,
@@ -1000,7 +1026,9 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
         // ------------------------------------------------------------------ lambda wave
         int seen_ready = 0, seen = 0;
         bool ok = pair_wait_ge(&sync.ready, 1, &sync.abort, seen_ready);
-        const double2 pN = psi_final[lane];
+        double fr[1] = {psi_final[lane].x}, fi[1] = {psi_final[lane].y};
+        basis_change<N, false>(fr, fi, pauli, lane);
+        const double2 pN = make_double2(fr[0], fi[0]);
         const double h = ham_weight<N>(klow, off, co, diag);
         double gb;
         {
@@ -1012,6 +1040,7 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
         }
         if (!valid) gb = 0.0;
         double lr[1] = {gb * h * pN.x}, li[1] = {gb * h * pN.y};
+        basis_change<N, true>(lr, li, pauli, lane);
 
         GradSums<N> sums;
         sums.sub_w = -1; sums.col_x = -1; sums.m_x = 0; sums.red = red_lds; sums.lane = lane; sums.wave = wave;
@@ -1092,12 +1121,12 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
 // ---------------------------------------------------------------------------------------
 struct FwdArgs {
     Runs runs; long B; int E; const double2* cs; const char* gates; int gates_bytes; double off, co;
-    const double* diag; double* out; double* state_out; const double* bias;
+    const double* diag; double* out; double* state_out; const double* bias; int pauli;
 };
 struct BwdArgs {
     Runs runs; long B; int E; int blk; const double2* cs; const char* gates; int gates_bytes; double off, co;
     const double* diag; const double* g; const double* state_in; const double* y; const double* bias; double inv_bt;
-    double* out; double* grad_x; double* partial;
+    double* out; double* grad_x; double* partial; int pauli;
 };
 
 #ifdef QHEA_SUBSET      // development builds: -D'QHEA_SUBSET(X)=X(2) X(5)' links only those qubit counts

@@ -12,17 +12,17 @@ namespace qhea {
 
 void QHEA_CAT(launch_fwd_, QHEA_N)(dim3 grid, hipStream_t st, const FwdArgs& a) {
     hipLaunchKernelGGL(fwd_kernel<QHEA_N>, grid, dim3(kWaves * 64), 0, st, a.runs, a.B, a.E, a.cs, a.gates, a.gates_bytes, a.off,
-                       a.co, a.diag, a.out, a.state_out, a.bias);
+                       a.co, a.diag, a.pauli, a.out, a.state_out, a.bias);
 }
 void QHEA_CAT(launch_bwd_, QHEA_N)(dim3 grid, hipStream_t st, const BwdArgs& a) {
     hipLaunchKernelGGL(bwd_kernel<QHEA_N>, grid, dim3(kWaves * 64), 0, st, a.runs, a.B, a.E, a.blk, a.cs, a.gates, a.gates_bytes,
-                       a.off, a.co, a.diag, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out, a.grad_x, a.partial);
+                       a.off, a.co, a.diag, a.pauli, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out, a.grad_x, a.partial);
 }
 
 void QHEA_CAT(launch_bwd_pair_, QHEA_N)(dim3 grid, hipStream_t st, const BwdArgs& a) {
 #if QHEA_N <= 5
     hipLaunchKernelGGL(bwd_pair_kernel<QHEA_N>, grid, dim3(128), 0, st, a.runs, a.B, a.E, a.blk, a.cs, a.gates,
-                       a.gates_bytes, a.off, a.co, a.diag, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out, a.grad_x,
+                       a.gates_bytes, a.off, a.co, a.diag, a.pauli, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out, a.grad_x,
                        a.partial);
 #else
     (void)grid; (void)st; (void)a;      // never selected for n > 5 (hea_api.hip: make_layout)

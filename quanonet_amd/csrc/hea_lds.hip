@@ -113,6 +113,16 @@ __device__ void forward_lds(double2* psi, int n, const Runs& runs, const double2
     }
 }
 
+// readout-basis change on every qubit (see basis_change in hea_device.hpp): X -> RY(-pi/2), Y -> RX(+pi/2)
+__device__ void basis_lds(double2* s, int n, int pauli, bool dag) {
+    if (pauli == 0) return;
+    const double r = 0.70710678118654752440, sr = dag ? -r : r;
+    const double4 u = pauli == 1 ? make_double4(r, 0.0, sr, 0.0) : make_double4(r, 0.0, 0.0, -sr);
+    int q = 0;
+    for (; q + 1 < n; q += 2) pass2(s, n, q, q + 1, u, u);
+    if (q < n) pass1(s, n, q, u);
+}
+
 __device__ __forceinline__ double ham_w(int k, int n, double off, double co, const double* __restrict__ diag) {
     return diag ? diag[k] : off + co * (double)(n - 2 * (int)__popc((unsigned)k));
 }
@@ -131,19 +141,22 @@ __device__ __forceinline__ double block_sum(double v, double* scratch /*[4]*/) {
 
 __global__ __launch_bounds__(kT) void lds_fwd_kernel(int n, Runs runs, long B, int E, const double2* __restrict__ cs,
                                                      const char* __restrict__ gates, double off, double co,
-                                                     const double* __restrict__ diag, double* __restrict__ out,
-                                                     double* __restrict__ state_out, const double* __restrict__ bias) {
+                                                     const double* __restrict__ diag, int pauli,
+                                                     double* __restrict__ out, double* __restrict__ state_out,
+                                                     const double* __restrict__ bias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2* psi = reinterpret_cast<double2*>(smem);
     double* scratch = reinterpret_cast<double*>(smem + ((size_t)16 << n));
     const long b = blockIdx.x;
     forward_lds(psi, n, runs, cs + b * E, gates);
     const int dim = 1 << n;
+    if (state_out)
+        for (int k = threadIdx.x; k < dim; k += kT) reinterpret_cast<double2*>(state_out)[(b << n) + k] = psi[k];
+    basis_lds(psi, n, pauli, false);
     double acc = 0.0;
     for (int k = threadIdx.x; k < dim; k += kT) {
         const double2 a = psi[k];
         acc += ham_w(k, n, off, co, diag) * (a.x * a.x + a.y * a.y);
-        if (state_out) reinterpret_cast<double2*>(state_out)[(b << n) + k] = a;
     }
     const double tot = block_sum(acc, scratch);
     if (threadIdx.x == 0) out[b] = tot + (bias ? bias[0] : 0.0);
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(kT) void lds_fwd_kernel(int n, Runs runs, long B, i
 template <int KW>
 __global__ __launch_bounds__(kT) void lds_bwd_kernel(int n, Runs runs, long B, int E, int blk,
                                                      const double2* __restrict__ cs, const char* __restrict__ gates,
-                                                     double off, double co, const double* __restrict__ diag,
+                                                     double off, double co, const double* __restrict__ diag, int pauli,
                                                      const double* __restrict__ g, const double* __restrict__ state_in,
                                                      const double* __restrict__ y, const double* __restrict__ bias,
                                                      double inv_bt, double* __restrict__ out,
@@ -173,6 +186,7 @@ __global__ __launch_bounds__(kT) void lds_bwd_kernel(int n, Runs runs, long B, i
     } else {
         forward_lds(psi, n, runs, cs_b, gates);
     }
+    basis_lds(psi, n, pauli, false);
     double acc = 0.0;
     for (int k = threadIdx.x; k < dim; k += kT) {
         const double2 a = psi[k];
@@ -187,6 +201,8 @@ __global__ __launch_bounds__(kT) void lds_bwd_kernel(int n, Runs runs, long B, i
         lam[k] = make_double2(h * a.x, h * a.y);
     }
     __syncthreads();
+    basis_lds(psi, n, pauli, true);
+    basis_lds(lam, n, pauli, true);
 
     double* __restrict__ part_b = partial + b * (long)blk * KW;
     int col = E, sub = blk;
@@ -281,7 +297,7 @@ int launch_lds_fwd(int n, long B, hipStream_t st, const FwdArgs& a) {
         attr_done = true;
     }
     hipLaunchKernelGGL(lds_fwd_kernel, dim3((unsigned)B), dim3(kT), smem, st, n, a.runs, a.B, a.E, a.cs, a.gates, a.off,
-                       a.co, a.diag, a.out, a.state_out, a.bias);
+                       a.co, a.diag, a.pauli, a.out, a.state_out, a.bias);
     return QHEA_OK;
 }
 
@@ -295,7 +311,7 @@ static int launch_bwd_kw(int n, long B, hipStream_t st, const BwdArgs& a) {
         attr_done = true;
     }
     hipLaunchKernelGGL(lds_bwd_kernel<KW>, dim3((unsigned)B), dim3(kT), lds_bwd_smem(n), st, n, a.runs, a.B, a.E, a.blk,
-                       a.cs, a.gates, a.off, a.co, a.diag, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out, a.grad_x,
+                       a.cs, a.gates, a.off, a.co, a.diag, a.pauli, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out, a.grad_x,
                        a.partial);
     return QHEA_OK;
 }

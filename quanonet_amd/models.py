@@ -49,14 +49,14 @@ class _ScaleRepeat(nn.Module):
 
 
 def _build_quantum_layer(quantum_backend, num_qubits, total_input_size, net_size, ham_bound, ham_diag,
-                         branch_input_size=None, trunk_input_size=None, dtype=torch.float64):
+                         branch_input_size=None, trunk_input_size=None, dtype=torch.float64, ham_pauli='Z'):
     """String-keyed plug-in dispatch (core/models_pt.py:71-100); only the HIP backend lives here."""
     if quantum_backend in HIP_BACKENDS:
         if branch_input_size is not None:
             return build_quanonet_hip(num_qubits, branch_input_size, trunk_input_size, net_size,
-                                      ham_bound=ham_bound, ham_diag=ham_diag, dtype=dtype)
+                                      ham_bound=ham_bound, ham_diag=ham_diag, dtype=dtype, ham_pauli=ham_pauli)
         return build_heaqnn_hip(num_qubits, total_input_size, net_size,
-                                ham_bound=ham_bound, ham_diag=ham_diag, dtype=dtype)
+                                ham_bound=ham_bound, ham_diag=ham_diag, dtype=dtype, ham_pauli=ham_pauli)
     raise ValueError(f"Unknown quantum_backend for PyTorch models: '{quantum_backend}'")
 
 
@@ -65,7 +65,7 @@ class QuanONetPT(nn.Module):
 
     def __init__(self, num_qubits, branch_input_size, trunk_input_size, net_size,
                  scale_coeff=1.0, if_trainable_freq=False, quantum_backend='hip',
-                 ham_bound=(-5.0, 5.0), ham_diag=None, dtype=torch.float64):
+                 ham_bound=(-5.0, 5.0), ham_diag=None, dtype=torch.float64, ham_pauli='Z'):
         super().__init__()
         branch_depth, branch_linear_depth, trunk_depth, trunk_linear_depth = net_size
         self.num_qubits = num_qubits
@@ -83,7 +83,8 @@ class QuanONetPT(nn.Module):
             quantum_backend, num_qubits,
             total_input_size=self.trunk_enc_size + self.branch_enc_size,
             net_size=net_size, ham_bound=ham_bound, ham_diag=ham_diag,
-            branch_input_size=branch_input_size, trunk_input_size=trunk_input_size, dtype=dtype)
+            branch_input_size=branch_input_size, trunk_input_size=trunk_input_size, dtype=dtype,
+            ham_pauli=ham_pauli)
         self.bias = nn.Parameter(torch.zeros(1, dtype=dtype))
 
     def fused_desc(self):
@@ -92,7 +93,7 @@ class QuanONetPT(nn.Module):
         return _lib.make_model_desc(_lib.MODEL_QUANONET, self.num_qubits, self.net_size,
                                     self.branch_freq.in_features, self.trunk_freq.in_features,
                                     self.if_trainable_freq, getattr(self.branch_freq, 'scale', 0.0),
-                                    q.ham_offset, q.ham_coeff)
+                                    q.ham_offset, q.ham_coeff, getattr(q, 'ham_pauli', 0))
 
     def forward(self, branch_input, trunk_input):
         branch_enc = self.branch_freq(branch_input)
@@ -105,7 +106,8 @@ class HEAQNNPT(nn.Module):
     """out = Q(F(x)), no bias   (core/models_pt.py:169-213)."""
 
     def __init__(self, num_qubits, input_size, net_size, scale_coeff=1.0, if_trainable_freq=False,
-                 quantum_backend='hip', ham_bound=(-5.0, 5.0), ham_diag=None, dtype=torch.float64):
+                 quantum_backend='hip', ham_bound=(-5.0, 5.0), ham_diag=None, dtype=torch.float64,
+                 ham_pauli='Z'):
         super().__init__()
         depth = net_size[0]
         enc_size = depth * num_qubits
@@ -118,13 +120,13 @@ class HEAQNNPT(nn.Module):
             self.freq = _ScaleRepeat(input_size, enc_size, scale_coeff)
         self.quantum_layer = _build_quantum_layer(
             quantum_backend, num_qubits, total_input_size=enc_size,
-            net_size=net_size, ham_bound=ham_bound, ham_diag=ham_diag, dtype=dtype)
+            net_size=net_size, ham_bound=ham_bound, ham_diag=ham_diag, dtype=dtype, ham_pauli=ham_pauli)
 
     def fused_desc(self):
         q = self.quantum_layer
         return _lib.make_model_desc(_lib.MODEL_HEAQNN, self.num_qubits, self.net_size[:2], self.freq.in_features, 0,
                                     self.if_trainable_freq, getattr(self.freq, 'scale', 0.0),
-                                    q.ham_offset, q.ham_coeff)
+                                    q.ham_offset, q.ham_coeff, getattr(q, 'ham_pauli', 0))
 
     def forward(self, x):
         return self.quantum_layer(self.freq(x))

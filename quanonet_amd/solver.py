@@ -201,13 +201,17 @@ class PTSolver:
         if_tf = str(c.get('if_trainable_freq', 'true')).lower() == 'true'
         scale = float(c.get('scale_coeff', 0.01))
         n = int(c['num_qubits'])
+        # --ham_diag strictly overrides --ham_pauli (utils/common.py:84)
+        ham_pauli = 'Z' if c.get('ham_diag') is not None else (c.get('ham_pauli') or 'Z')
         if self.model_type == 'QuanONet':
             return QuanONetPT(n, self.data_dict['train_branch_input'].shape[1],
                               self.data_dict['train_trunk_input'].shape[1], net_size, scale_coeff=scale,
-                              if_trainable_freq=if_tf, ham_bound=ham_bound, ham_diag=c.get('ham_diag'))
+                              if_trainable_freq=if_tf, ham_bound=ham_bound, ham_diag=c.get('ham_diag'),
+                              ham_pauli=ham_pauli)
         if self.model_type == 'HEAQNN':
             return HEAQNNPT(n, self.data_dict['train_input'].shape[1], net_size, scale_coeff=scale,
-                            if_trainable_freq=if_tf, ham_bound=ham_bound, ham_diag=c.get('ham_diag'))
+                            if_trainable_freq=if_tf, ham_bound=ham_bound, ham_diag=c.get('ham_diag'),
+                            ham_pauli=ham_pauli)
         raise ValueError(f"PTSolver does not support model_type='{self.model_type}'")
 
     def _dev(self, a):

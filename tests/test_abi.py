@@ -41,7 +41,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.qhea_version() >= 100
+    assert lib.qhea_version() >= 200
     assert lib.qhea_strerror(0) == b'ok'
     assert b'invalid' in lib.qhea_strerror(-1)
     assert b'workspace' in lib.qhea_strerror(-3)
@@ -57,11 +57,16 @@ def test_shape_validation_without_gpu(lib):
     bad = (i32 * 3)(5, -1, 5)
     assert lib.qhea_workspace_bytes(5, 3, bad, ld, 8) == 0
     # argument errors are reported before anything touches a device
-    assert lib.qhea_forward(1, 3, enc, ld, 4, None, None, 0.0, 1.0, None, None, None, None, 0, None) == -1
-    assert lib.qhea_forward(5, 3, enc, ld, 4, None, None, 0.0, 1.0, None, None, None, None, 0, None) == -1
-    assert lib.qhea_backward(5, 3, enc, ld, -1, None, None, 0.0, 1.0, None, None, None, None, None, None,
+    assert lib.qhea_forward(1, 3, enc, ld, 4, None, None, 0.0, 1.0, None, 0, None, None, None, 0, None) == -1
+    assert lib.qhea_forward(5, 3, enc, ld, 4, None, None, 0.0, 1.0, None, 0, None, None, None, 0, None) == -1
+    assert lib.qhea_backward(5, 3, enc, ld, -1, None, None, 0.0, 1.0, None, 0, None, None, None, None, None,
                              None, 0, None) == -1
-    assert lib.qhea_forward(5, 3, enc, ld, 0, None, None, 0.0, 1.0, None, None, None, None, 0, None) == 0   # empty batch
+    assert lib.qhea_forward(5, 3, enc, ld, 0, None, None, 0.0, 1.0, None, 0, None, None, None, 0, None) == 0   # empty batch
+    # read-out Pauli: 0/1/2 = Z/X/Y; anything else, or X/Y together with a ham_diag pointer, is rejected
+    assert lib.qhea_forward(5, 3, enc, ld, 0, None, None, 0.0, 1.0, None, 2, None, None, None, 0, None) == 0
+    assert lib.qhea_forward(5, 3, enc, ld, 0, None, None, 0.0, 1.0, None, 3, None, None, None, 0, None) == -1
+    assert lib.qhea_forward(5, 3, enc, ld, 0, None, None, 0.0, 1.0, ctypes.c_void_p(64), 1, None, None, None, 0,
+                            None) == -1
     # more than 16 distinct (enc, ld) runs is outside this build's kernel-argument budget
     many_e = (i32 * 40)(*[5] * 40)
     many_l = (i32 * 40)(*[(i % 2) + 1 for i in range(40)])
@@ -84,6 +89,13 @@ def test_model_descriptor(lib):
     bad = _lib.make_model_desc(7, 5, (1, 1, 1, 1), 3, 1, True, 0.1, 0.0, 1.0)
     with pytest.raises(_lib.QheaError):
         _lib.model_param_count(bad)
+    dy = _lib.make_model_desc(_lib.MODEL_QUANONET, 5, (40, 2, 20, 2), 100, 2, True, 0.1, 0.0, 1.0, ham_pauli='Y')
+    assert dy.ham_pauli == 2 and _lib.model_param_count(dy) == 2401
+    dy.ham_pauli = 5
+    with pytest.raises(_lib.QheaError):
+        _lib.model_param_count(dy)
+    with pytest.raises(ValueError):
+        _lib.pauli_code('W')
 
 
 def test_device_count_matches_torch(lib):

@@ -24,13 +24,14 @@ def _t(a, dev):
     return torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
 
 
-def _run(n, cfgs, x, w, g, dev, off, co, diag=None, use_state=True):
+def _run(n, cfgs, x, w, g, dev, off, co, diag=None, use_state=True, pauli='Z'):
     from quanonet_amd import _lib
     sh = _lib.CircuitShape(n, cfgs)
     xd, wd, gd = _t(x, dev), _t(w, dev), _t(g, dev)
     dd = None if diag is None else _t(diag, dev)
-    out, st = _lib.hea_forward(sh, xd, wd, off, co, dd, return_state=True)
-    gx, gw, out2 = _lib.hea_backward(sh, xd, wd, gd, off, co, dd, state=st if use_state else None, want_out=True)
+    out, st = _lib.hea_forward(sh, xd, wd, off, co, dd, return_state=True, ham_pauli=pauli)
+    gx, gw, out2 = _lib.hea_backward(sh, xd, wd, gd, off, co, dd, state=st if use_state else None, want_out=True,
+                                     ham_pauli=pauli)
     torch.cuda.synchronize()
     return (out.cpu().numpy(), st.cpu().numpy(), gx.cpu().numpy(), gw.cpu().numpy(), out2.cpu().numpy())
 
@@ -112,6 +113,75 @@ def test_ham_diag_readout(dev):
     np.testing.assert_allclose(out, ro, atol=TOL)
     np.testing.assert_allclose(gx, rgx, atol=TOL)
     np.testing.assert_allclose(gw, rgw, atol=TOL)
+
+
+@pytest.mark.parametrize('pauli', ['X', 'Y'])
+@pytest.mark.parametrize('n', [2, 4, 5, 6, 8, 10, 12])
+def test_pauli_xy_readout(dev, n, pauli, backward_variant):
+    """H = offset + coeff * sum_i P_i for P = X, Y (generate_simple_hamiltonian's `pauli`,
+    core/quantum_circuits_ms.py:28-39).  The oracle applies the Paulis one by one; the kernels rotate the
+    measurement basis.  state_out stays psi_N (before that rotation)."""
+    if n > 5 and backward_variant == 'pair':
+        pytest.skip("wave-pair kernel exists for n <= 5 only")
+    rng = np.random.default_rng(500 + n)
+    cfgs = [(n, 2), (n + 1, 1)]
+    E, blk = O.circuit_sizes(n, cfgs)
+    B = 7 if n >= 9 else 3 * max(1, 64 >> n) + 2
+    x = rng.uniform(-np.pi, np.pi, (B, E))
+    w = rng.uniform(-np.pi, np.pi, (blk, 3, n))
+    g = rng.normal(size=B)
+    off, co = O.ham_params(n, -2.0, 6.0)
+    ro, rst = C.hea_forward(n, cfgs, x, w, off, co, return_state=True, ham_pauli=pauli)
+    _, rgx, rgw = C.hea_backward(n, cfgs, x, w, g, off, co, ham_pauli=pauli)
+    for use_state in (True, False):
+        out, st, gx, gw, out2 = _run(n, cfgs, x, w, g, dev, off, co, use_state=use_state, pauli=pauli)
+        np.testing.assert_allclose(out, ro, rtol=0, atol=TOL)
+        np.testing.assert_allclose(out2, ro, rtol=0, atol=TOL)
+        np.testing.assert_allclose(st, rst, rtol=0, atol=TOL)
+        np.testing.assert_allclose(gx, rgx, rtol=0, atol=TOL)
+        np.testing.assert_allclose(gw, rgw, rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize('pauli', ['X', 'Y'])
+def test_pauli_xy_lds_kernels_and_model_path(dev, pauli, monkeypatch):
+    from quanonet_amd.models import QuanONetPT
+    from quanonet_amd.solver import DataParallelTrainer
+    from quanonet_amd import _lib
+    # fused model path + autograd module path, n = 5
+    torch.manual_seed(11)
+    n, net, b_in, t_in, B = 5, (3, 2, 2, 1), 6, 2, 37
+    model = QuanONetPT(n, b_in, t_in, net, scale_coeff=0.1, if_trainable_freq=True, ham_pauli=pauli).to(dev)
+    rng = np.random.default_rng(17)
+    br = rng.normal(size=(B, b_in)); tr = rng.uniform(size=(B, t_in)); y = rng.normal(size=B)
+    with torch.no_grad():
+        model.bias.fill_(-0.2)
+    fused = DataParallelTrainer(model, lr=1e-3, fused=True)
+    flat = fused.loss_and_grad(_t(br, dev), _t(tr, dev), _t(y, dev)).clone()
+    pred = _lib.model_forward(fused.desc, _t(br, dev), _t(tr, dev), fused.pflat).cpu().numpy()
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    rl, rg, ro = O.quanonet_loss_and_grads(sd, br, tr, y, n, net, ham_pauli=pauli)
+    ref = np.concatenate([rg[k].reshape(-1) for k, _ in model.named_parameters()])
+    np.testing.assert_allclose(pred, ro, rtol=0, atol=TOL)
+    np.testing.assert_allclose(flat[:-2].cpu().numpy(), ref, rtol=0, atol=TOL)
+    auto = DataParallelTrainer(model, lr=1e-3, fused=False)
+    flat2 = auto.loss_and_grad(_t(br, dev), _t(tr, dev), _t(y, dev).unsqueeze(-1))
+    np.testing.assert_allclose(flat.cpu().numpy(), flat2.cpu().numpy(), rtol=0, atol=TOL)
+    # LDS-resident kernels forced on
+    monkeypatch.setenv('QHEA_LDS_KERNEL', 'force')
+    n, cfgs = 5, [(5, 2), (7, 1)]
+    E, blk = O.circuit_sizes(n, cfgs)
+    x = rng.uniform(-3, 3, (9, E)); w = rng.uniform(-3, 3, (blk, 3, n)); g = rng.normal(size=9)
+    ro, rgx, rgw = C.hea_backward(n, cfgs, x, w, g, 0.4, 1.3, ham_pauli=pauli)
+    for use_state in (True, False):
+        out, st, gx, gw, out2 = _run(n, cfgs, x, w, g, dev, 0.4, 1.3, use_state=use_state, pauli=pauli)
+        np.testing.assert_allclose(out, ro, rtol=0, atol=TOL)
+        np.testing.assert_allclose(out2, ro, rtol=0, atol=TOL)
+        np.testing.assert_allclose(gx, rgx, rtol=0, atol=TOL)
+        np.testing.assert_allclose(gw, rgw, rtol=0, atol=TOL)
+    # X/Y together with a diagonal Hamiltonian is an argument error
+    sh = _lib.CircuitShape(n, cfgs)
+    with pytest.raises(_lib.QheaError):
+        _lib.hea_forward(sh, _t(x, dev), _t(w, dev), 0.0, 1.0, _t(np.ones(32), dev), ham_pauli=pauli)
 
 
 def test_edge_shapes(dev, backward_variant):
