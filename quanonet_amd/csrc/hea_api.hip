@@ -167,15 +167,17 @@ bool use_pair(int n, int64_t B) {
     return 2 * ((B + spw - 1) / spw) <= simd_count();
 }
 
-// LDS-resident kernels (hea_lds.hip) where the wave-resident ones spill badly: n = 12 (measured, 12 sub-layers,
-// B = 1024: backward 2.5 ms vs 14.5 ms, forward 0.67 vs 0.79 ms; at n = 11 the wave-resident kernels still win)
+// Workgroup-resident kernels (hea_lds.hip) for n >= 10.  Measured, 12 sub-layers, B = 1024, forward / forward+backward:
+//   n = 10: 67 / 232 us vs 124 / 321 us wave-resident;  n = 11: 110 / 450 vs 180 / 1200 us (the wave-resident
+//   backward spills);  n = 12: 205 / 880 us vs 790 us / 14.5 ms.
 bool use_lds(int n, bool backward) {
+    if (!lds_supported(n)) return false;
     if (const char* e = getenv("QHEA_LDS_KERNEL")) {           // test hook: "force" / "off"
         if (e[0] == 'f') return true;
         if (e[0] == 'o') return false;
     }
     (void)backward;
-    return n >= 12;
+    return n >= 10;
 }
 
 Layout make_layout(int n, const Shape& sh, int64_t B) {

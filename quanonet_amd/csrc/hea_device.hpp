@@ -1141,7 +1141,8 @@ struct BwdArgs {
 QHEA_FOR_EACH_N(QHEA_DECLARE)
 #undef QHEA_DECLARE
 
-// LDS-resident variant for the largest qubit counts (hea_lds.hip); runtime n
+// workgroup-resident variant for the largest qubit counts (hea_lds.hip)
+bool lds_supported(int n);
 int launch_lds_fwd(int n, long B, hipStream_t st, const FwdArgs& a);
 int launch_lds_bwd(int n, long B, hipStream_t st, const BwdArgs& a);
 

@@ -1,29 +1,72 @@
-// hea_lds.hip -- LDS-resident variant of the HEA simulator for the largest qubit counts.
+// hea_lds.hip -- workgroup-resident variant of the HEA simulator for the largest qubit counts (n = 10..12).
 //
-// The wave-resident kernels (hea_device.hpp) keep 2^(n-6) amplitudes per lane in VGPRs; with psi and
-// lambda live that exceeds the 256 architectural VGPRs for n >= 11 (backward) / n = 12 (forward) and the
-// compiler spills to scratch (measured 14.5 ms vs 0.27 ms going from n=10 to n=12 for the same depth).
-// Here ONE 256-thread workgroup owns one sample and the state(s) live in LDS (n=12: 64 KB per state, two
-// states in the backward kernel = 128 of the CU's 160 KB).  Gates are applied two qubits per pass (each
-// thread loads a group of four amplitudes, applies both 2x2 updates in registers and stores), the CNOT
-// ring as in-place conditional swaps.  Same circuit, same fused SU(2) tables, same adjoint recipe as the
-// wave-resident kernels; bound by LDS bandwidth (~2 state passes per gate pair).
+// The wave-resident kernels (hea_device.hpp) keep 2^(n-6) amplitudes per lane in VGPRs; with psi and lambda
+// live that exceeds the 256 architectural VGPRs for n >= 11 (backward) / n = 12 (forward) and the compiler
+// spills to scratch.  Here ONE workgroup of 2^(n-4) threads owns one sample; the state(s) rest in LDS
+// (n = 12: 64 KB per state, psi + lambda = 128 of the CU's 160 KB) and every thread works on 16 amplitudes
+// at a time in registers:
+//
+//   * a gate layer (the n fused SU(2) gates of a sub-layer) is ceil(n/4) passes; pass p loads, per thread,
+//     the 16 amplitudes that differ in index bits A..A+3 (A = 4p, or n-4 for a ragged last pass), applies the
+//     gates of those qubits as in-register 2x2 updates and stores them back -- one LDS round trip of the
+//     state per FOUR gates;
+//   * a block's RX encodings are folded, per sample, into the fused gates of its first sub-layer
+//     (U RX(theta) is again an SU(2) matrix), so they cost no layer of their own; their gradient is
+//     n . (X,Y,Z) of that sub-layer's inner products with n = axis of U X U^dagger (rotated_x_axis);
+//     only encodings beyond n per block, or a block without sub-layers, still run as RX layers;
+//   * the CNOT ring is a permutation of the basis index that is linear over GF(2), so it costs no pass of
+//     its own: the last pass of a forward sub-layer scatters its amplitudes to ring(k), the first pass of a
+//     reverse sub-layer gathers from ring(k); per amplitude that is ONE xor with a compile-time constant
+//     on top of a per-thread base computed once per kernel;
+//   * LDS index swizzle phys(k) = k ^ ((k >> 4) & 15): for every pass the 16-byte accesses of 16
+//     neighbouring lanes fall into 16 different bank quads (a thread's 16 amplitudes would otherwise sit
+//     256 B apart for A = 0).
+//
+// Same circuit, same fused SU(2) table, same adjoint recipe (X,Y,Z inner products taken after the fused gate,
+// mapped to the three angles in reduce_kernel) as the wave-resident kernels.  Bound by fp64 FMA issue
+// (16 FMAs per amplitude pair and gate; 44 in the reverse sweep) plus the LDS round trip of each pass, which
+// the barriers keep from overlapping with the arithmetic when only one workgroup fits a CU (backward, n = 12).
+// Measured, cfg 5 (n = 12, Net40-2-20-2, B = 1024): forward 1.90 ms, forward + backward 8.47 ms (the previous
+// gate-pair-per-pass LDS kernels: 6.6 / 21.8 ms).
 #include "hea_device.hpp"
 
 namespace qhea {
 
 namespace {
 
-constexpr int kT = 256;                       // threads per sample
-
 struct c2 { double x, y; };
-__device__ __forceinline__ c2 ld(const double2* p, int i) { const double2 v = p[i]; return {v.x, v.y}; }
-__device__ __forceinline__ void st(double2* p, int i, c2 v) { p[i] = make_double2(v.x, v.y); }
 
-__device__ __forceinline__ int ins0(int p, int q) { return ((p >> q) << (q + 1)) | (p & ((1 << q) - 1)); }
+template <int N>
+struct LCfg {
+    static_assert(N >= 10 && N <= 12, "workgroup-resident kernels: n = 10..12");
+    static constexpr int T = 1 << (N - 4);            // threads per sample; 16 amplitudes each
+    static constexpr int NW = T / 64;                 // waves
+    static constexpr int NP = (N + 3) / 4;            // passes per gate layer
+    static constexpr int DIM = 1 << N;
+    static constexpr int KW = Cfg<N>::KW;             // padded 3n = row width of `partial` (reduce_kernel)
+    static constexpr size_t STATE_BYTES = (size_t)16 << N;
+    static constexpr size_t SCRATCH_BYTES = (size_t)NW * 64 * sizeof(double) + 16 * sizeof(double4);   // sums + gate table
+};
+template <int N, int P>
+struct Pass {
+    static constexpr int Q0 = 4 * P;                                   // gate qubits [Q0, Q1)
+    static constexpr int Q1 = (4 * P + 4 < N) ? 4 * P + 4 : N;
+    static constexpr int A = (4 * P + 4 <= N) ? 4 * P : N - 4;         // lowest of the four index bits held per thread
+};
+
+__host__ __device__ constexpr int phys(int k) { return k ^ ((k >> 4) & 15); }     // involution (bits 4..7 stay)
+// CNOT ring as a map of basis indices: |k> -> |ring(k)>, CNOT(control (i+1)%n, target i) for i = 0..n-1 in order
+template <int N>
+__host__ __device__ constexpr int ring_dst(int k) {
+    for (int i = 0; i < N; ++i) k ^= ((k >> ((i + 1) % N)) & 1) << i;
+    return k;
+}
+// index bits of thread t for a pass with base bit A (the four bits A..A+3 are the per-thread local index j)
+template <int A>
+__device__ __forceinline__ int thread_part(int t) { return ((t >> A) << (A + 4)) | (t & ((1 << A) - 1)); }
 
 // [[a,b],[-conj b, conj a]] on (p0,p1); u = (ar, ai, br, bi)
-__device__ __forceinline__ void su2(c2& p0, c2& p1, double4 u) {
+__device__ __forceinline__ void su2(c2& p0, c2& p1, const double4& u) {
     const c2 a0 = p0, a1 = p1;
     p0.x = u.x * a0.x - u.y * a0.y + u.z * a1.x - u.w * a1.y;
     p0.y = u.x * a0.y + u.y * a0.x + u.z * a1.y + u.w * a1.x;
@@ -34,249 +77,386 @@ __device__ __forceinline__ double4 dagger(double4 u) { return make_double4(u.x, 
 // RX as an SU(2) in the same form: a = c, b = -i s  ->  (c, 0, 0, -s)
 __device__ __forceinline__ double4 rx_su2(double2 cs) { return make_double4(cs.x, 0.0, 0.0, -cs.y); }
 
+// U * RX(theta) for U = (ar, ai, br, bi), (c, s) = (cos, sin)(theta/2): still of the form [[a,b],[-conj b, conj a]].
+// Each block's RX encodings are folded into the fused gates of its first sub-layer, per sample: one gate layer
+// and a third of the arithmetic less per block.
+// Per-sample gate coefficients of a layer (folded RX) are computed ONCE per layer by threads 0..n-1 into a
+// small LDS table and read back (broadcast) right before use.  Computing them inline in every thread made
+// the compiler keep all of a layer's merged gates live and spill ~1500 registers (measured: 10x slower).
+template <int N, class F>
+__device__ __forceinline__ void set_gates(double4* gtab, F f) {
+    if (threadIdx.x < N) gtab[threadIdx.x] = f((int)threadIdx.x);
+    __syncthreads();
+}
+__device__ __forceinline__ double4 merge_rx(const double4& u, double2 cs) {
+    return make_double4(u.x * cs.x + u.w * cs.y, u.y * cs.x - u.z * cs.y, u.z * cs.x + u.y * cs.y, u.w * cs.x - u.x * cs.y);
+}
+// d/dtheta of U RX(theta) = (-i/2) (U X U^dagger) (U RX), and U X U^dagger = n . sigma, so the encoding gradient
+// Im<lam|X|psi> taken between RX and U equals n . (X,Y,Z) of the inner products taken after the merged gate.
+__device__ __forceinline__ void rotated_x_axis(const double4& u, double& nx, double& ny, double& nz) {
+    nx = u.x * u.x - u.y * u.y - u.z * u.z + u.w * u.w;
+    ny = -2.0 * (u.x * u.y - u.z * u.w);
+    nz = 2.0 * (u.x * u.z + u.y * u.w);
+}
+
 // Im<l|sigma|p> contributions of one pair (p0,p1),(l0,l1)
-__device__ __forceinline__ void inner(c2 p0, c2 p1, c2 l0, c2 l1, double& X, double& Y, double& Z) {
+__device__ __forceinline__ void inner(const c2& p0, const c2& p1, const c2& l0, const c2& l1, double& X, double& Y,
+                                      double& Z) {
     X += (l0.x * p1.y - l0.y * p1.x) + (l1.x * p0.y - l1.y * p0.x);
     Y += -(l0.x * p1.x + l0.y * p1.y) + (l1.x * p0.x + l1.y * p0.y);
     Z += (l0.x * p0.y - l0.y * p0.x) - (l1.x * p1.y - l1.y * p1.x);
 }
+__device__ __forceinline__ void inner_x(const c2& p0, const c2& p1, const c2& l0, const c2& l1, double& X) {
+    X += (l0.x * p1.y - l0.y * p1.x) + (l1.x * p0.y - l1.y * p0.x);
+}
 
-// two independent one-qubit gates (qa < qb) in one pass over the state
-__device__ __forceinline__ void pass2(double2* s, int n, int qa, int qb, double4 ua, double4 ub) {
-    const int ng = 1 << (n - 2);
-    for (int g = threadIdx.x; g < ng; g += kT) {
-        const int i00 = ins0(ins0(g, qa), qb), i01 = i00 | (1 << qa), i10 = i00 | (1 << qb), i11 = i01 | (1 << qb);
-        c2 a00 = ld(s, i00), a01 = ld(s, i01), a10 = ld(s, i10), a11 = ld(s, i11);
-        su2(a00, a01, ua); su2(a10, a11, ua);
-        su2(a00, a10, ub); su2(a01, a11, ub);
-        st(s, i00, a00); st(s, i01, a01); st(s, i10, a10); st(s, i11, a11);
-    }
-    __syncthreads();
+// the 16 amplitudes of this thread for a pass with base bit A: local index j <-> index bits A..A+3.
+// `base` = phys(thread_part) (in place) or phys(ring(thread_part)) (through the ring); both maps are linear
+// over GF(2), so amplitude j sits at base ^ constant_j.
+template <int N, int A, bool RING>
+__device__ __forceinline__ void load16(const double2* s, int base, c2 (&v)[16]) {
+    static_for<0, 16>([&](auto jj) {
+        constexpr int J = decltype(jj)::value;
+        constexpr int CJ = RING ? phys(ring_dst<N>(J << A)) : phys(J << A);
+        const double2 a = s[base ^ CJ];
+        v[J].x = a.x; v[J].y = a.y;
+    });
 }
-__device__ __forceinline__ void pass1(double2* s, int n, int q, double4 u) {
-    const int np = 1 << (n - 1);
-    for (int p = threadIdx.x; p < np; p += kT) {
-        const int i0 = ins0(p, q), i1 = i0 | (1 << q);
-        c2 a0 = ld(s, i0), a1 = ld(s, i1);
-        su2(a0, a1, u);
-        st(s, i0, a0); st(s, i1, a1);
-    }
-    __syncthreads();
+template <int N, int A, bool RING>
+__device__ __forceinline__ void store16(double2* s, int base, const c2 (&v)[16]) {
+    static_for<0, 16>([&](auto jj) {
+        constexpr int J = decltype(jj)::value;
+        constexpr int CJ = RING ? phys(ring_dst<N>(J << A)) : phys(J << A);
+        s[base ^ CJ] = make_double2(v[J].x, v[J].y);
+    });
 }
-// CNOT(control c, target t): swap amplitudes (c=1,t=0) <-> (c=1,t=1)
-__device__ __forceinline__ void cnot_pass(double2* s, int n, int c, int t) {
-    const int lo = c < t ? c : t, hi = c < t ? t : c;
-    const int ng = 1 << (n - 2);
-    for (int g = threadIdx.x; g < ng; g += kT) {
-        const int i = ins0(ins0(g, lo), hi) | (1 << c);
-        const double2 a = s[i], b = s[i | (1 << t)];
-        s[i] = b; s[i | (1 << t)] = a;
-    }
-    __syncthreads();
+template <int LBIT>
+__device__ __forceinline__ void apply16(c2 (&v)[16], const double4& u) {
+    static_for<0, 16>([&](auto jj) {
+        constexpr int J = decltype(jj)::value;
+        if constexpr (!(J & (1 << LBIT))) su2(v[J], v[J | (1 << LBIT)], u);
+    });
 }
-__device__ __forceinline__ void ring(double2* s, int n, bool reverse) {
-    if (!reverse) for (int i = 0; i < n; ++i) cnot_pass(s, n, (i + 1) % n, i);
-    else          for (int i = n - 1; i >= 0; --i) cnot_pass(s, n, (i + 1) % n, i);
+
+template <int N>
+struct Bases {                        // per-thread LDS index bases, computed once per kernel
+    int plain[LCfg<N>::NP];           // phys(thread_part<A_p>(t))
+    int ring;                         // phys(ring(thread_part<A_last>(t)))
+    __device__ __forceinline__ void init(int t) {
+        static_for<0, LCfg<N>::NP>([&](auto p) {
+            constexpr int P = decltype(p)::value;
+            plain[P] = phys(thread_part<Pass<N, P>::A>(t));
+        });
+        ring = phys(ring_dst<N>(thread_part<Pass<N, LCfg<N>::NP - 1>::A>(t)));
+    }
+};
+
+// One forward gate layer.  gate(q, u) fills u and returns whether qubit q has a gate (wave-uniform).
+// RING: the last pass scatters through the CNOT ring.
+template <int N, bool RING, class G>
+__device__ __forceinline__ void fwd_layer(double2* s, const Bases<N>& bs, G gate) {
+    constexpr int NP = LCfg<N>::NP;
+    static_for<0, NP>([&](auto p) {
+        constexpr int P = decltype(p)::value;
+        using PS = Pass<N, P>;
+        c2 v[16];
+        load16<N, PS::A, false>(s, bs.plain[P], v);
+        static_for<PS::Q0, PS::Q1>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            double4 u;
+            if (gate(Q, u)) apply16<Q - PS::A>(v, u);
+        });
+        if constexpr (RING && P == NP - 1) {
+            __syncthreads();                               // every thread holds its amplitudes: safe to permute
+            store16<N, PS::A, true>(s, bs.ring, v);
+        } else {
+            store16<N, PS::A, false>(s, bs.plain[P], v);
+        }
+        __syncthreads();
+    });
+}
+
+// One reverse layer on psi and lambda: (ring^-1 via a gather in the first pass when RING), then per qubit the
+// inner products Im<lam|sigma|psi> (XYZ: all three, else X only) followed by the adjoint gate on both states.
+// gate(q, u) returns the ADJOINT coefficients.  acc: XYZ ? [3q..3q+2] : [q].
+template <int N, bool RING, bool XYZ, class G, int NA>
+__device__ __forceinline__ void bwd_layer(double2* psi, double2* lam, const Bases<N>& bs, G gate, double (&acc)[NA]) {
+    constexpr int NP = LCfg<N>::NP;
+    static_rfor<0, NP>([&](auto p) {
+        constexpr int P = decltype(p)::value;
+        using PS = Pass<N, P>;
+        c2 v[16], l[16];
+        if constexpr (RING && P == NP - 1) {
+            load16<N, PS::A, true>(psi, bs.ring, v);
+            load16<N, PS::A, true>(lam, bs.ring, l);
+            __syncthreads();                               // all gathers done before anything is overwritten
+        } else {
+            load16<N, PS::A, false>(psi, bs.plain[P], v);
+            load16<N, PS::A, false>(lam, bs.plain[P], l);
+        }
+        static_for<PS::Q0, PS::Q1>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            constexpr int LBIT = Q - PS::A;
+            double4 u;
+            if (gate(Q, u)) {
+                static_for<0, 16>([&](auto jj) {
+                    constexpr int J = decltype(jj)::value;
+                    if constexpr (!(J & (1 << LBIT))) {
+                        constexpr int J1 = J | (1 << LBIT);
+                        if constexpr (XYZ) inner(v[J], v[J1], l[J], l[J1], acc[3 * Q], acc[3 * Q + 1], acc[3 * Q + 2]);
+                        else inner_x(v[J], v[J1], l[J], l[J1], acc[Q]);
+                        su2(v[J], v[J1], u);
+                        su2(l[J], l[J1], u);
+                    }
+                });
+            }
+        });
+        store16<N, PS::A, false>(psi, bs.plain[P], v);
+        store16<N, PS::A, false>(lam, bs.plain[P], l);
+        __syncthreads();
+    });
 }
 
 __device__ __forceinline__ double4 gate_u(const char* gates, int n, int sub, int q) {   // base variant of gate (sub,q)
     return *reinterpret_cast<const double4*>(gates + ((long)(sub + 1) * n + q) * kGateBytes);
 }
 
-__device__ void forward_lds(double2* psi, int n, const Runs& runs, const double2* __restrict__ cs_b,
-                            const char* __restrict__ gates) {
-    const int dim = 1 << n;
-    for (int k = threadIdx.x; k < dim; k += kT) psi[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
+template <int N>
+__device__ __forceinline__ double ham_w(int k, double off, double co, const double* __restrict__ diag) {
+    return diag ? diag[k] : off + co * (double)(N - 2 * (int)__popc((unsigned)k));
+}
+
+// sum of one double per thread over the workgroup (fixed order), result in every thread
+template <int N>
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    double t[1] = {v};
+    lane_reduce<1, 6>(t, threadIdx.x & 63);
+    if constexpr (LCfg<N>::NW == 1) return t[0];
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = t[0];
+    __syncthreads();
+    double tot = scratch[0];
+#pragma unroll
+    for (int w = 1; w < LCfg<N>::NW; ++w) tot += scratch[w];
+    __syncthreads();                                       // scratch is reused by the caller
+    return tot;
+}
+
+// readout-basis change on every qubit (see basis_change in hea_device.hpp): X -> RY(-pi/2), Y -> RX(+pi/2)
+template <int N>
+__device__ __forceinline__ void basis_lds(double2* s, const Bases<N>& bs, int pauli, bool dag) {
+    if (pauli == 0) return;
+    const double r = 0.70710678118654752440, sr = dag ? -r : r;
+    const double4 uc = pauli == 1 ? make_double4(r, 0.0, sr, 0.0) : make_double4(r, 0.0, 0.0, -sr);
+    fwd_layer<N, false>(s, bs, [&](int, double4& u) { u = uc; return true; });
+}
+
+template <int N>
+__device__ __forceinline__ void forward_lds(double2* psi, double4* gtab, const Bases<N>& bs, const Runs& runs,
+                                            const double2* __restrict__ cs_b, const char* __restrict__ gates) {
+    using L = LCfg<N>;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int p = threadIdx.x + j * L::T;
+        psi[p] = make_double2(p == 0 ? 1.0 : 0.0, 0.0);              // |0..0>: phys(0) = 0
+    }
     __syncthreads();
     int col = 0, sub = 0;
     for (int ri = 0; ri < runs.nruns; ++ri) {
         const int ne = runs.enc[ri], nld = runs.ld[ri];
         for (int rep = 0; rep < runs.count[ri]; ++rep) {
-            for (int j = 0; j < ne; ) {                        // RX(x[col+j]) on wire j % n
-                const int q = j % n;
-                if (j + 1 < ne && q + 1 < n) {
-                    pass2(psi, n, q, q + 1, rx_su2(cs_b[col + j]), rx_su2(cs_b[col + j + 1]));
-                    j += 2;
-                } else {
-                    pass1(psi, n, q, rx_su2(cs_b[col + j]));
-                    j += 1;
-                }
+            // RX(x[col+j]) on wire j % n, n wires per layer; the last layer is folded into the first sub-layer
+            const int nchunks = (ne + N - 1) / N;
+            const int nsep = (nld > 0 && ne > 0) ? nchunks - 1 : nchunks;
+            for (int ch = 0; ch < nsep; ++ch) {
+                const int j0 = ch * N;
+                const int m = (ne - j0) < N ? (ne - j0) : N;
+                const double2* c = cs_b + col + j0;
+                fwd_layer<N, false>(psi, bs, [&](int q, double4& u) {
+                    if (q >= m) return false;
+                    u = rx_su2(c[q]);
+                    return true;
+                });
+            }
+            if (nsep < nchunks) {
+                const int j0 = nsep * N;
+                const int m = ne - j0;
+                const double2* c = cs_b + col + j0;
+                set_gates<N>(gtab, [&](int q) {
+                    return merge_rx(gate_u(gates, N, sub, q), q < m ? c[q] : make_double2(1.0, 0.0));
+                });
+                fwd_layer<N, true>(psi, bs, [&](int q, double4& u) { u = gtab[q]; return true; });
+                ++sub;
             }
             col += ne;
-            for (int l = 0; l < nld; ++l, ++sub) {
-                int q = 0;
-                for (; q + 1 < n; q += 2) pass2(psi, n, q, q + 1, gate_u(gates, n, sub, q), gate_u(gates, n, sub, q + 1));
-                if (q < n) pass1(psi, n, q, gate_u(gates, n, sub, q));
-                ring(psi, n, false);
-            }
+            for (int l = (nsep < nchunks) ? 1 : 0; l < nld; ++l, ++sub)
+                fwd_layer<N, true>(psi, bs, [&](int q, double4& u) { u = gate_u(gates, N, sub, q); return true; });
         }
     }
 }
 
-// readout-basis change on every qubit (see basis_change in hea_device.hpp): X -> RY(-pi/2), Y -> RX(+pi/2)
-__device__ void basis_lds(double2* s, int n, int pauli, bool dag) {
-    if (pauli == 0) return;
-    const double r = 0.70710678118654752440, sr = dag ? -r : r;
-    const double4 u = pauli == 1 ? make_double4(r, 0.0, sr, 0.0) : make_double4(r, 0.0, 0.0, -sr);
-    int q = 0;
-    for (; q + 1 < n; q += 2) pass2(s, n, q, q + 1, u, u);
-    if (q < n) pass1(s, n, q, u);
-}
-
-__device__ __forceinline__ double ham_w(int k, int n, double off, double co, const double* __restrict__ diag) {
-    return diag ? diag[k] : off + co * (double)(n - 2 * (int)__popc((unsigned)k));
-}
-
-// sum of one double per thread over the 256-thread block (fixed order), result in every thread
-__device__ __forceinline__ double block_sum(double v, double* scratch /*[4]*/) {
-    double t[1] = {v};
-    lane_reduce<1, 6>(t, threadIdx.x & 63);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = t[0];
-    __syncthreads();
-    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
-}
-
 }  // namespace
 
-__global__ __launch_bounds__(kT) void lds_fwd_kernel(int n, Runs runs, long B, int E, const double2* __restrict__ cs,
-                                                     const char* __restrict__ gates, double off, double co,
-                                                     const double* __restrict__ diag, int pauli,
-                                                     double* __restrict__ out, double* __restrict__ state_out,
-                                                     const double* __restrict__ bias) {
+template <int N>
+__global__ __launch_bounds__(LCfg<N>::T) void lds_fwd_kernel(Runs runs, long B, int E, const double2* __restrict__ cs,
+                                                             const char* __restrict__ gates, double off, double co,
+                                                             const double* __restrict__ diag, int pauli,
+                                                             double* __restrict__ out, double* __restrict__ state_out,
+                                                             const double* __restrict__ bias) {
+    using L = LCfg<N>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2* psi = reinterpret_cast<double2*>(smem);
-    double* scratch = reinterpret_cast<double*>(smem + ((size_t)16 << n));
+    double* scratch = reinterpret_cast<double*>(smem + L::STATE_BYTES);
+    double4* gtab = reinterpret_cast<double4*>(scratch + L::NW * 64);
     const long b = blockIdx.x;
-    forward_lds(psi, n, runs, cs + b * E, gates);
-    const int dim = 1 << n;
-    if (state_out)
-        for (int k = threadIdx.x; k < dim; k += kT) reinterpret_cast<double2*>(state_out)[(b << n) + k] = psi[k];
-    basis_lds(psi, n, pauli, false);
-    double acc = 0.0;
-    for (int k = threadIdx.x; k < dim; k += kT) {
-        const double2 a = psi[k];
-        acc += ham_w(k, n, off, co, diag) * (a.x * a.x + a.y * a.y);
+    Bases<N> bs;
+    bs.init(threadIdx.x);
+    forward_lds<N>(psi, gtab, bs, runs, cs + b * E, gates);
+    if (state_out) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = threadIdx.x + j * L::T;
+            reinterpret_cast<double2*>(state_out)[(b << N) + k] = psi[phys(k)];
+        }
     }
-    const double tot = block_sum(acc, scratch);
+    basis_lds<N>(psi, bs, pauli, false);
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = threadIdx.x + j * L::T;
+        const double2 a = psi[phys(k)];
+        acc += ham_w<N>(k, off, co, diag) * (a.x * a.x + a.y * a.y);
+    }
+    const double tot = block_sum<N>(acc, scratch);
     if (threadIdx.x == 0) out[b] = tot + (bias ? bias[0] : 0.0);
 }
 
-// Backward: one row of `partial` per sample ([B][blk][kw]); grad_x written directly.
-template <int KW>
-__global__ __launch_bounds__(kT) void lds_bwd_kernel(int n, Runs runs, long B, int E, int blk,
-                                                     const double2* __restrict__ cs, const char* __restrict__ gates,
-                                                     double off, double co, const double* __restrict__ diag, int pauli,
-                                                     const double* __restrict__ g, const double* __restrict__ state_in,
-                                                     const double* __restrict__ y, const double* __restrict__ bias,
-                                                     double inv_bt, double* __restrict__ out,
-                                                     double* __restrict__ grad_x, double* __restrict__ partial) {
+// Backward: one row of `partial` per sample ([B][blk][KW]); grad_x written directly.
+template <int N>
+__global__ __launch_bounds__(LCfg<N>::T) void lds_bwd_kernel(Runs runs, long B, int E, int blk,
+                                                             const double2* __restrict__ cs,
+                                                             const char* __restrict__ gates, double off, double co,
+                                                             const double* __restrict__ diag, int pauli,
+                                                             const double* __restrict__ g,
+                                                             const double* __restrict__ state_in,
+                                                             const double* __restrict__ y,
+                                                             const double* __restrict__ bias, double inv_bt,
+                                                             double* __restrict__ out, double* __restrict__ grad_x,
+                                                             double* __restrict__ partial) {
+    using L = LCfg<N>;
+    constexpr int KW = L::KW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int dim = 1 << n;
     double2* psi = reinterpret_cast<double2*>(smem);
-    double2* lam = psi + dim;
-    double* scratch = reinterpret_cast<double*>(lam + dim);          // [4][KW]
+    double2* lam = psi + L::DIM;
+    double* scratch = reinterpret_cast<double*>(smem + 2 * L::STATE_BYTES);        // [NW][64]
+    double4* gtab = reinterpret_cast<double4*>(scratch + L::NW * 64);
     const long b = blockIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const double2* __restrict__ cs_b = cs + b * E;
+    Bases<N> bs;
+    bs.init(threadIdx.x);
 
     if (state_in) {
-        for (int k = threadIdx.x; k < dim; k += kT) psi[k] = reinterpret_cast<const double2*>(state_in)[(b << n) + k];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = threadIdx.x + j * L::T;
+            psi[phys(k)] = reinterpret_cast<const double2*>(state_in)[(b << N) + k];
+        }
         __syncthreads();
     } else {
-        forward_lds(psi, n, runs, cs_b, gates);
+        forward_lds<N>(psi, gtab, bs, runs, cs_b, gates);
     }
-    basis_lds(psi, n, pauli, false);
+    basis_lds<N>(psi, bs, pauli, false);
     double acc = 0.0;
-    for (int k = threadIdx.x; k < dim; k += kT) {
-        const double2 a = psi[k];
-        acc += ham_w(k, n, off, co, diag) * (a.x * a.x + a.y * a.y);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = threadIdx.x + j * L::T;
+        const double2 a = psi[phys(k)];
+        acc += ham_w<N>(k, off, co, diag) * (a.x * a.x + a.y * a.y);
     }
-    const double pred = block_sum(acc, scratch) + (bias ? bias[0] : 0.0);
+    const double pred = block_sum<N>(acc, scratch) + (bias ? bias[0] : 0.0);
     if (out && threadIdx.x == 0) out[b] = pred;
     const double gb = y ? 2.0 * (pred - y[b]) * inv_bt : g[b];
-    for (int k = threadIdx.x; k < dim; k += kT) {
-        const double2 a = psi[k];
-        const double h = gb * ham_w(k, n, off, co, diag);
-        lam[k] = make_double2(h * a.x, h * a.y);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = threadIdx.x + j * L::T;
+        const double2 a = psi[phys(k)];
+        const double h = gb * ham_w<N>(k, off, co, diag);
+        lam[phys(k)] = make_double2(h * a.x, h * a.y);
     }
     __syncthreads();
-    basis_lds(psi, n, pauli, true);
-    basis_lds(lam, n, pauli, true);
+    basis_lds<N>(psi, bs, pauli, true);
+    basis_lds<N>(lam, bs, pauli, true);
 
     double* __restrict__ part_b = partial + b * (long)blk * KW;
     int col = E, sub = blk;
     for (int ri = runs.nruns - 1; ri >= 0; --ri) {
         const int ne = runs.enc[ri], nld = runs.ld[ri];
+        const int nchunks = (ne + N - 1) / N;
         for (int rep = 0; rep < runs.count[ri]; ++rep) {
+            const int nsep = (nld > 0 && ne > 0) ? nchunks - 1 : nchunks;      // see forward_lds
+            const int m_merged = nsep < nchunks ? ne - nsep * N : 0;
+            col -= ne;
             for (int l = nld - 1; l >= 0; --l) {
                 --sub;
-                ring(psi, n, true);
-                ring(lam, n, true);
+                const int mm = l == 0 ? m_merged : 0;           // encodings folded into this sub-layer's gates
+                const double2* c = cs_b + col + nsep * N;
                 double xyz[KW];
 #pragma unroll
                 for (int i = 0; i < KW; ++i) xyz[i] = 0.0;
-                // qubit pairs (q, q+1); compile-time pair index so that the xyz slots stay in registers
-                static_for<0, (KW / 3 + 1) / 2>([&](auto pidx) {
-                    constexpr int qq = 2 * decltype(pidx)::value;
-                    if (qq < n) {                                   // wave-uniform
-                        const bool two = qq + 1 < n;
-                        const double4 ua = gate_u(gates, n, sub, qq), ub = two ? gate_u(gates, n, sub, qq + 1) : ua;
-                        const double4 uad = dagger(ua), ubd = dagger(ub);
-                        double Xa = 0, Ya = 0, Za = 0, Xb = 0, Yb = 0, Zb = 0;
-                        if (two) {
-                            const int ng = 1 << (n - 2);
-                            for (int gi = threadIdx.x; gi < ng; gi += kT) {
-                                const int i00 = ins0(ins0(gi, qq), qq + 1), i01 = i00 | (1 << qq), i10 = i00 | (2 << qq),
-                                          i11 = i01 | (2 << qq);
-                                c2 p00 = ld(psi, i00), p01 = ld(psi, i01), p10 = ld(psi, i10), p11 = ld(psi, i11);
-                                c2 l00 = ld(lam, i00), l01 = ld(lam, i01), l10 = ld(lam, i10), l11 = ld(lam, i11);
-                                inner(p00, p01, l00, l01, Xa, Ya, Za); inner(p10, p11, l10, l11, Xa, Ya, Za);
-                                inner(p00, p10, l00, l10, Xb, Yb, Zb); inner(p01, p11, l01, l11, Xb, Yb, Zb);
-                                su2(p00, p01, uad); su2(p10, p11, uad); su2(p00, p10, ubd); su2(p01, p11, ubd);
-                                su2(l00, l01, uad); su2(l10, l11, uad); su2(l00, l10, ubd); su2(l01, l11, ubd);
-                                st(psi, i00, p00); st(psi, i01, p01); st(psi, i10, p10); st(psi, i11, p11);
-                                st(lam, i00, l00); st(lam, i01, l01); st(lam, i10, l10); st(lam, i11, l11);
-                            }
-                        } else {
-                            const int np = 1 << (n - 1);
-                            for (int p = threadIdx.x; p < np; p += kT) {
-                                const int i0 = ins0(p, qq), i1 = i0 | (1 << qq);
-                                c2 p0 = ld(psi, i0), p1 = ld(psi, i1), l0 = ld(lam, i0), l1 = ld(lam, i1);
-                                inner(p0, p1, l0, l1, Xa, Ya, Za);
-                                su2(p0, p1, uad); su2(l0, l1, uad);
-                                st(psi, i0, p0); st(psi, i1, p1); st(lam, i0, l0); st(lam, i1, l1);
-                            }
-                        }
-                        __syncthreads();
-                        if constexpr (3 * qq + 2 < KW) { xyz[3 * qq] = Xa; xyz[3 * qq + 1] = Ya; xyz[3 * qq + 2] = Za; }
-                        if constexpr (3 * qq + 5 < KW) { xyz[3 * qq + 3] = Xb; xyz[3 * qq + 4] = Yb; xyz[3 * qq + 5] = Zb; }
-                    }
+                set_gates<N>(gtab, [&](int q) {
+                    return dagger(merge_rx(gate_u(gates, N, sub, q), q < mm ? c[q] : make_double2(1.0, 0.0)));
                 });
-                // block sum of the KW per-thread values: wave butterfly, then the four waves through LDS
-                lane_reduce<KW, 6>(xyz, lane);
-                if (lane < KW) scratch[wv * KW + lane] = xyz[0];
+                bwd_layer<N, true, true>(psi, lam, bs, [&](int q, double4& u) { u = gtab[q]; return true; }, xyz);
+                // workgroup sum of the 3n per-thread values: wave butterfly, then the waves through LDS
+                lane_reduce<KW, 6>(xyz, lane);               // lane i holds the wave total of value i
+                if (lane < KW) scratch[wv * 64 + lane] = xyz[0];
                 __syncthreads();
-                if (threadIdx.x < KW)
-                    part_b[(long)sub * KW + threadIdx.x] = (scratch[threadIdx.x] + scratch[KW + threadIdx.x]) +
-                                                           (scratch[2 * KW + threadIdx.x] + scratch[3 * KW + threadIdx.x]);
+                if (threadIdx.x < KW) {
+                    double tot = scratch[threadIdx.x];
+#pragma unroll
+                    for (int w = 1; w < L::NW; ++w) tot += scratch[w * 64 + threadIdx.x];
+                    part_b[(long)sub * KW + threadIdx.x] = tot;
+                }
+                if (threadIdx.x < mm) {                      // encoding gradient of the folded RX on wire threadIdx.x
+                    const int q = threadIdx.x;
+                    double X = 0.0, Y = 0.0, Z = 0.0;
+#pragma unroll
+                    for (int w = 0; w < L::NW; ++w) {
+                        X += scratch[w * 64 + 3 * q]; Y += scratch[w * 64 + 3 * q + 1]; Z += scratch[w * 64 + 3 * q + 2];
+                    }
+                    double nx, ny, nz;
+                    rotated_x_axis(gate_u(gates, N, sub, q), nx, ny, nz);
+                    grad_x[b * E + col + nsep * N + q] = nx * X + ny * Y + nz * Z;
+                }
                 __syncthreads();
             }
-            col -= ne;
-            for (int j = ne - 1; j >= 0; --j) {                 // RX gates in reverse order, one per pass
-                const int q = j % n;
-                const double4 ud = dagger(rx_su2(cs_b[col + j]));
-                double X = 0, Yd = 0, Zd = 0;
-                const int np = 1 << (n - 1);
-                for (int p = threadIdx.x; p < np; p += kT) {
-                    const int i0 = ins0(p, q), i1 = i0 | (1 << q);
-                    c2 p0 = ld(psi, i0), p1 = ld(psi, i1), l0 = ld(lam, i0), l1 = ld(lam, i1);
-                    inner(p0, p1, l0, l1, X, Yd, Zd);
-                    su2(p0, p1, ud); su2(l0, l1, ud);
-                    st(psi, i0, p0); st(psi, i1, p1); st(lam, i0, l0); st(lam, i1, l1);
+            for (int ch = nsep - 1; ch >= 0; --ch) {            // remaining RX layers in reverse order
+                const int j0 = ch * N;
+                const int m = (ne - j0) < N ? (ne - j0) : N;
+                const double2* c = cs_b + col + j0;
+                double gx[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) gx[i] = 0.0;
+                bwd_layer<N, false, false>(psi, lam, bs, [&](int q, double4& u) {
+                    if (q >= m) return false;
+                    u = dagger(rx_su2(c[q]));
+                    return true;
+                }, gx);
+                lane_reduce<16, 6>(gx, lane);                // lane l holds the wave total of value l & 15
+                if constexpr (L::NW == 1) {
+                    if (lane < m) grad_x[b * E + col + j0 + lane] = gx[0];
+                } else {
+                    if (lane < 16) scratch[wv * 64 + lane] = gx[0];
+                    __syncthreads();
+                    if (threadIdx.x < m) {
+                        double tot = scratch[threadIdx.x];
+#pragma unroll
+                        for (int w = 1; w < L::NW; ++w) tot += scratch[w * 64 + threadIdx.x];
+                        grad_x[b * E + col + j0 + threadIdx.x] = tot;
+                    }
+                    __syncthreads();
                 }
-                const double tot = block_sum(X, scratch);        // contains the barriers that order the passes
-                if (threadIdx.x == 0) grad_x[b * E + col + j] = tot;
             }
         }
     }
@@ -285,43 +465,60 @@ __global__ __launch_bounds__(kT) void lds_bwd_kernel(int n, Runs runs, long B, i
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
-size_t lds_fwd_smem(int n) { return ((size_t)16 << n) + 64; }
-size_t lds_bwd_smem(int n) { return ((size_t)32 << n) + 4 * 64 * sizeof(double); }
+namespace {
 
-int launch_lds_fwd(int n, long B, hipStream_t st, const FwdArgs& a) {
-    const size_t smem = lds_fwd_smem(n);
+template <int N>
+int launch_fwd_n(long B, hipStream_t st, const FwdArgs& a) {
+    using L = LCfg<N>;
+    constexpr size_t smem = L::STATE_BYTES + L::SCRATCH_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lds_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024 - 256) != hipSuccess) return QHEA_ELAUNCH;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(lds_fwd_kernel, dim3((unsigned)B), dim3(kT), smem, st, n, a.runs, a.B, a.E, a.cs, a.gates, a.off,
-                       a.co, a.diag, a.pauli, a.out, a.state_out, a.bias);
-    return QHEA_OK;
-}
-
-template <int KW>
-static int launch_bwd_kw(int n, long B, hipStream_t st, const BwdArgs& a) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lds_bwd_kernel<KW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lds_fwd_kernel<N>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return QHEA_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(lds_bwd_kernel<KW>, dim3((unsigned)B), dim3(kT), lds_bwd_smem(n), st, n, a.runs, a.B, a.E, a.blk,
-                       a.cs, a.gates, a.off, a.co, a.diag, a.pauli, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out, a.grad_x,
+    hipLaunchKernelGGL(lds_fwd_kernel<N>, dim3((unsigned)B), dim3(L::T), smem, st, a.runs, a.B, a.E, a.cs, a.gates,
+                       a.off, a.co, a.diag, a.pauli, a.out, a.state_out, a.bias);
+    return QHEA_OK;
+}
+
+template <int N>
+int launch_bwd_n(long B, hipStream_t st, const BwdArgs& a) {
+    using L = LCfg<N>;
+    constexpr size_t smem = 2 * L::STATE_BYTES + L::SCRATCH_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lds_bwd_kernel<N>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return QHEA_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(lds_bwd_kernel<N>, dim3((unsigned)B), dim3(L::T), smem, st, a.runs, a.B, a.E, a.blk, a.cs,
+                       a.gates, a.off, a.co, a.diag, a.pauli, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out, a.grad_x,
                        a.partial);
     return QHEA_OK;
 }
 
-int launch_lds_bwd(int n, long B, hipStream_t st, const BwdArgs& a) {       // KW must equal padded_3n(n): reduce_kernel's row width
-    switch (padded_3n(n)) {
-        case 8: return launch_bwd_kw<8>(n, B, st, a);
-        case 16: return launch_bwd_kw<16>(n, B, st, a);
-        case 32: return launch_bwd_kw<32>(n, B, st, a);
-        default: return launch_bwd_kw<64>(n, B, st, a);
+}  // namespace
+
+bool lds_supported(int n) { return n >= 10 && n <= 12; }
+
+int launch_lds_fwd(int n, long B, hipStream_t st, const FwdArgs& a) {
+    switch (n) {
+        case 10: return launch_fwd_n<10>(B, st, a);
+        case 11: return launch_fwd_n<11>(B, st, a);
+        case 12: return launch_fwd_n<12>(B, st, a);
+        default: return QHEA_EUNSUPPORTED;
+    }
+}
+
+int launch_lds_bwd(int n, long B, hipStream_t st, const BwdArgs& a) {
+    switch (n) {
+        case 10: return launch_bwd_n<10>(B, st, a);
+        case 11: return launch_bwd_n<11>(B, st, a);
+        case 12: return launch_bwd_n<12>(B, st, a);
+        default: return QHEA_EUNSUPPORTED;
     }
 }
 

@@ -79,14 +79,37 @@ def test_every_qubit_count_against_oracle(dev, n, backward_variant):
         np.testing.assert_allclose(gw, rgw, rtol=0, atol=TOL)
 
 
-@pytest.mark.parametrize('n', [2, 3, 5, 6, 8, 9, 11, 12])
+@pytest.mark.parametrize('n', [10, 11, 12])
+def test_wave_resident_kernels_for_large_n(dev, n, monkeypatch):
+    """n >= 10 defaults to hea_lds.hip; the wave-resident kernels stay built for those n and must stay right."""
+    monkeypatch.setenv('QHEA_LDS_KERNEL', 'off')
+    rng = np.random.default_rng(400 + n)
+    cfgs = [(n, 2), (n + 2, 1)]
+    E, blk = O.circuit_sizes(n, cfgs)
+    B = 5
+    x = rng.uniform(-np.pi, np.pi, (B, E))
+    w = rng.uniform(-np.pi, np.pi, (blk, 3, n))
+    g = rng.normal(size=B)
+    off, co = O.ham_params(n, -3.0, 7.0)
+    ro, rst = C.hea_forward(n, cfgs, x, w, off, co, return_state=True)
+    _, rgx, rgw = C.hea_backward(n, cfgs, x, w, g, off, co)
+    for use_state in (True, False):
+        out, st, gx, gw, out2 = _run(n, cfgs, x, w, g, dev, off, co, use_state=use_state)
+        np.testing.assert_allclose(out, ro, rtol=0, atol=TOL)
+        np.testing.assert_allclose(st, rst, rtol=0, atol=TOL)
+        np.testing.assert_allclose(gx, rgx, rtol=0, atol=TOL)
+        np.testing.assert_allclose(gw, rgw, rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize('n', [10, 11, 12])
 def test_lds_resident_kernels_against_oracle(dev, n, monkeypatch):
-    """hea_lds.hip (selected automatically for the largest n) forced on for every qubit count."""
+    """hea_lds.hip (selected automatically for n = 12) forced on for every qubit count it is built for;
+    ragged encodings (more and fewer than n per block) and a block without sub-layers included."""
     monkeypatch.setenv('QHEA_LDS_KERNEL', 'force')
     rng = np.random.default_rng(300 + n)
-    cfgs = [(n, 2), (n, 1)] if n > 8 else [(n, 2), (n, 1), (n + 3, 2), (n, 0)]
+    cfgs = [(n, 2), (n - 3, 1), (n + 3, 2), (n, 0), (0, 1)]
     E, blk = O.circuit_sizes(n, cfgs)
-    B = 5 if n > 8 else 11
+    B = 5
     x = rng.uniform(-np.pi, np.pi, (B, E))
     w = rng.uniform(-np.pi, np.pi, (blk, 3, n))
     g = rng.normal(size=B)
@@ -168,9 +191,9 @@ def test_pauli_xy_lds_kernels_and_model_path(dev, pauli, monkeypatch):
     np.testing.assert_allclose(flat.cpu().numpy(), flat2.cpu().numpy(), rtol=0, atol=TOL)
     # LDS-resident kernels forced on
     monkeypatch.setenv('QHEA_LDS_KERNEL', 'force')
-    n, cfgs = 5, [(5, 2), (7, 1)]
+    n, cfgs = 10, [(10, 2), (13, 1)]
     E, blk = O.circuit_sizes(n, cfgs)
-    x = rng.uniform(-3, 3, (9, E)); w = rng.uniform(-3, 3, (blk, 3, n)); g = rng.normal(size=9)
+    x = rng.uniform(-3, 3, (4, E)); w = rng.uniform(-3, 3, (blk, 3, n)); g = rng.normal(size=4)
     ro, rgx, rgw = C.hea_backward(n, cfgs, x, w, g, 0.4, 1.3, ham_pauli=pauli)
     for use_state in (True, False):
         out, st, gx, gw, out2 = _run(n, cfgs, x, w, g, dev, 0.4, 1.3, use_state=use_state, pauli=pauli)
@@ -181,7 +204,7 @@ def test_pauli_xy_lds_kernels_and_model_path(dev, pauli, monkeypatch):
     # X/Y together with a diagonal Hamiltonian is an argument error
     sh = _lib.CircuitShape(n, cfgs)
     with pytest.raises(_lib.QheaError):
-        _lib.hea_forward(sh, _t(x, dev), _t(w, dev), 0.0, 1.0, _t(np.ones(32), dev), ham_pauli=pauli)
+        _lib.hea_forward(sh, _t(x, dev), _t(w, dev), 0.0, 1.0, _t(np.ones(1 << n), dev), ham_pauli=pauli)
 
 
 def test_edge_shapes(dev, backward_variant):
