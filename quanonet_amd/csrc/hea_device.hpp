@@ -427,6 +427,28 @@ __device__ __forceinline__ void basis_change(double (&re)[Cfg<N>::R], double (&i
     }
 }
 
+// RX fold: a block's first RX chunk is folded, per sample, into the fused gates of the block's first sub-layer.
+// U RX(theta) is again [[a,b],[-conj b, conj a]], and the formula holds unchanged for the lane-specialised variant
+// (ar, s*ai, s*br, bi).  The merge is done ONCE per block on the gate table's copy in the wave's LDS ring
+// (GateStream::fold: ~15 instructions, every lane merges 16 bytes) instead of per lane and gate -- the first
+// attempt, merging in registers inside a second copy of the sub-layer body, cost 8 VALU per gate and ~200 VGPRs.
+// Only with one sample per wave (n >= 6).  The encoding gradient Im<lam|X|psi> taken between RX and U equals
+// n . (X,Y,Z) of the inner products taken after the merged gate, n = axis of U X U^dagger, so the reverse sweep needs
+// no RX phase and no extra inner products for the folded chunk.  For n <= 5 a wave carries several samples: the ring
+// would need a table copy per sample, the fold's three dependent LDS round trips cost more than the five cheap
+// one-register RX gates they replace (measured at n = 5: forward 58.8 vs 54 us), and the per-sample X,Y,Z sums the
+// reverse trick needs are the expensive ones -- so those kernels keep the separate RX phase.
+template <int N>
+constexpr bool kFold = Cfg<N>::SPW == 1;
+__device__ __forceinline__ double4 merge_rx(const double4& u, const double2& cs) {
+    return make_double4(u.x * cs.x + u.w * cs.y, u.y * cs.x - u.z * cs.y, u.z * cs.x + u.y * cs.y, u.w * cs.x - u.x * cs.y);
+}
+__device__ __forceinline__ void rotated_x_axis(const double4& u, double& nx, double& ny, double& nz) {
+    nx = u.x * u.x - u.y * u.y - u.z * u.z + u.w * u.w;
+    ny = -2.0 * (u.x * u.y - u.z * u.w);
+    nz = 2.0 * (u.x * u.z + u.y * u.w);
+}
+
 // ---------------------------------------------------------------------------------------
 // operand streams: gate coefficients (global, per-lane variant, rolling prefetch) and
 // per-sample RX (cos,sin) pairs (wave-private LDS window + one-block register prefetch)
@@ -445,10 +467,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRingBytesPerWave = 2 * QHEA_MAX_QUBITS * kGateBytes;      // two sub-layers
 
 template <int N>
+struct CsStream;
+
+template <int N>
 struct GateStream {
     using C = Cfg<N>;
     static constexpr bool SLOTS = N <= 8;
     static constexpr int SUBBYTES = N * kGateBytes;
+    static_assert(2 * SUBBYTES <= kRingBytesPerWave && 4 * N <= 64, "gate ring");
     double4 slot[SLOTS ? N : 1];
     u32x4 stage;                    // this lane's 16 B of the sub-layer in flight from global memory
     rsrc_t rsrc;
@@ -479,6 +505,14 @@ struct GateStream {
     __device__ __forceinline__ double4 pick(int s) const {          // this lane's variant of gate (s, Q)
         return *reinterpret_cast<const double4*>(buf(s) + Q * kGateBytes + voff[Q]);
     }
+    template <bool FWD>
+    __device__ __forceinline__ void repick() {                      // (re)load the register slots for sub-layer `sub`
+        if constexpr (SLOTS) {
+            static_for<0, N>([&](auto q) { slot[decltype(q)::value] = pick<decltype(q)::value>(sub); });
+        } else {
+            slot[0] = FWD ? pick<0>(sub) : pick<N - 1>(sub);
+        }
+    }
     // position at sub-layer s0 for a forward (dir +1) or reverse (dir -1) walk
     template <bool FWD>
     __device__ __forceinline__ void prime(int s0) {
@@ -487,11 +521,7 @@ struct GateStream {
         stage = gload(s0);
         park(s0);
         stage = gload(s0 + D);
-        if constexpr (SLOTS) {
-            static_for<0, N>([&](auto q) { slot[decltype(q)::value] = pick<decltype(q)::value>(s0); });
-        } else {
-            slot[0] = FWD ? pick<0>(s0) : pick<N - 1>(s0);
-        }
+        repick<FWD>();
     }
     // top of a sub-layer: park the next sub-layer's table (fetched one sub-layer ago), fetch the one after
     template <bool FWD>
@@ -500,6 +530,12 @@ struct GateStream {
         park(sub + D);
         stage = gload(sub + 2 * D);
     }
+    // RX fold (one sample per wave): gate g < m0 of the CURRENT sub-layer becomes U_g RX(x[col0 + g]) in the ring
+    // (both lane variants), then the register slots are reloaded.  Each loader lane owns half a variant, (ar, s ai)
+    // or (s br, bi), and its neighbour the other half; with own = (p0,p1), other = (q0,q1) both halves obey
+    // (p0 c + q1 s, p1 c - q0 s).  Call before begin() of that sub-layer; the CsStream window must cover the columns.
+    template <bool FWD>
+    __device__ __forceinline__ void fold(const CsStream<N>& csx, int col0, int m0, int lane);
     // use: u = gs.cur<FWD,Q>(); ...apply...; gs.done<FWD,Q>();
     template <bool FWD, int Q>
     __device__ __forceinline__ double4 cur() {
@@ -576,6 +612,20 @@ struct CsStream {
         static_for<0, N>([&](auto q) { nxt[decltype(q)::value] = p[decltype(q)::value]; });
     }
 };
+
+template <int N>
+template <bool FWD>
+__device__ __forceinline__ void GateStream<N>::fold(const CsStream<N>& csx, int col0, int m0, int lane) {
+    static_assert(kFold<N>, "one sample per wave");
+    const int g = lane >> 2;                                  // gate this lane's 16 B belong to
+    double2* mine = reinterpret_cast<double2*>(buf(sub) + lane16);
+    const double2 p = *mine;
+    const double q0 = xchg<1>(p.x), q1 = xchg<1>(p.y);
+    double2 cs = make_double2(1.0, 0.0);
+    if (loader && g < m0) cs = csx.lds[col0 + g - csx.lo];
+    if (loader) *mine = make_double2(p.x * cs.x + q1 * cs.y, p.y * cs.x - q0 * cs.y);
+    repick<FWD>();
+}
 
 // Deferred gradient sums of the backward kernel (N <= 5): values go through the wave's LDS scratch; the
 // additions and the store of sub-layer s / block b run one sub-layer / block later.
@@ -659,11 +709,15 @@ __device__ __forceinline__ void forward_sweep(double (&re)[Cfg<N>::R], double (&
     csx.template prefetch<true>(0);
     for (int ri = 0; ri < runs.nruns; ++ri) {
         const int ne = runs.enc[ri], nld = runs.ld[ri];
+        const bool fold = kFold<N> && nld > 0 && ne > 0;   // first RX chunk rides on the first sub-layer's gates
+        const int m0 = ne < N ? ne : N;
         for (int rep = 0; rep < runs.count[ri]; ++rep) {
-            static_for<0, N>([&](auto q) {
-                constexpr int Q = decltype(q)::value;
-                if (Q < ne) apply_rx<N, Q>(re, im, csx.nxt[Q].x, csx.nxt[Q].y);
-            });
+            if (!fold) {
+                static_for<0, N>([&](auto q) {
+                    constexpr int Q = decltype(q)::value;
+                    if (Q < ne) apply_rx<N, Q>(re, im, csx.nxt[Q].x, csx.nxt[Q].y);
+                });
+            }
             for (int j0 = N; j0 < ne; j0 += N) {          // more encodings than wires (not used by the reference)
                 const int m = (ne - j0) < N ? (ne - j0) : N;
                 csx.template need<true>(col + j0, m);
@@ -671,6 +725,12 @@ __device__ __forceinline__ void forward_sweep(double (&re)[Cfg<N>::R], double (&
                     constexpr int Q = decltype(q)::value;
                     if (Q < m) { const double2 c = csx.at(col + j0 + Q); apply_rx<N, Q>(re, im, c.x, c.y); }
                 });
+            }
+            if constexpr (kFold<N>) {
+                if (fold) {
+                    csx.template need<true>(col, m0);
+                    gs.template fold<true>(csx, col, m0, lane);
+                }
             }
             col += ne;
             csx.template prefetch<true>(col);              // next block's angles: two sub-layers of cover
@@ -820,10 +880,19 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
     for (int ri = runs.nruns - 1; ri >= 0; --ri) {
         const int ne = runs.enc[ri], nld = runs.ld[ri];
         const bool one_chunk = ne <= N;
+        const bool fold = kFold<N> && nld > 0 && ne > 0;   // the block's first RX chunk rides on sub-layer 0's gates
+        const int m0 = ne < N ? ne : N;
         for (int rep = 0; rep < runs.count[ri]; ++rep) {
-            if (one_chunk && ne > 0) csx.template prefetch<false>(col - ne);     // this block's angles, used after its sub-layers
+            if (one_chunk && !fold && ne > 0) csx.template prefetch<false>(col - ne);   // this block's angles, used after its sub-layers
             for (int l = nld - 1; l >= 0; --l) {
                 --sub;
+                const bool folded = fold && l == 0;
+                if constexpr (kFold<N>) {
+                    if (folded) {
+                        csx.template need<false>(col - ne, m0);
+                        gs.template fold<false>(csx, col - ne, m0, lane);
+                    }
+                }
                 apply_ring<N, true>(pr, pi, lane, ring_rev);
                 apply_ring<N, true>(lr, li, lane, ring_rev);
                 double acc3[C::KW];
@@ -842,12 +911,44 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
                 if constexpr (C::LDSRED) {
                     sums.put_w(acc3, sub);
                 } else {
-                    lane_reduce<C::KW, 6>(acc3, lane);
+                    lane_reduce<C::KW, 6>(acc3, lane);               // lane i holds the sample's total of value i
                     if (lane < C::KW) part_w[(long)sub * C::KW + lane] = acc3[0];
+                    if constexpr (kFold<N>) {
+                        if (folded) {                                // encoding gradients of the folded chunk: n . (X,Y,Z)
+                            const double Y = __shfl_down(acc3[0], 1), Z = __shfl_down(acc3[0], 2);
+                            const int q = lane / 3;
+                            if (lane % 3 == 0 && q < m0 && valid) {
+                                const double4 ub = *reinterpret_cast<const double4*>(gates + ((long)(sub + 1) * N + q) * kGateBytes);
+                                double nx, ny, nz;
+                                rotated_x_axis(ub, nx, ny, nz);
+                                grad_x[b * E + (col - ne) + q] = nx * acc3[0] + ny * Y + nz * Z;
+                            }
+                        }
+                    }
                 }
             }
             col -= ne;
-            if (one_chunk) {
+            if (fold) {
+                const int nchunks = (ne + N - 1) / N;
+                for (int ch = nchunks - 1; ch >= 1; --ch) {          // chunk 0 was folded
+                    const int j0 = ch * N;
+                    const int m = (ne - j0) < N ? (ne - j0) : N;
+                    csx.template need<false>(col + j0, m);
+                    double gx[C::KX];
+#pragma unroll
+                    for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
+                    static_rfor<0, N>([&](auto q) {
+                        constexpr int Q = decltype(q)::value;
+                        if (Q < m) {
+                            const double2 c = csx.at(col + j0 + Q);
+                            gx[Q] = pauli_x_inner<N, Q>(pr, pi, lr, li);
+                            apply_rx<N, Q>(pr, pi, c.x, -c.y);
+                            apply_rx<N, Q>(lr, li, c.x, -c.y);
+                        }
+                    });
+                    store_grad_x<N>(gx, lane, wave, B, E, grad_x, col + j0, m);
+                }
+            } else if (one_chunk) {
                 if (ne > 0) {
                     double gx[C::KX];
 #pragma unroll

@@ -77,9 +77,8 @@ __device__ __forceinline__ double4 dagger(double4 u) { return make_double4(u.x, 
 // RX as an SU(2) in the same form: a = c, b = -i s  ->  (c, 0, 0, -s)
 __device__ __forceinline__ double4 rx_su2(double2 cs) { return make_double4(cs.x, 0.0, 0.0, -cs.y); }
 
-// U * RX(theta) for U = (ar, ai, br, bi), (c, s) = (cos, sin)(theta/2): still of the form [[a,b],[-conj b, conj a]].
-// Each block's RX encodings are folded into the fused gates of its first sub-layer, per sample: one gate layer
-// and a third of the arithmetic less per block.
+// merge_rx / rotated_x_axis (the RX fold) are shared with the wave-resident kernels: hea_device.hpp
+
 // Per-sample gate coefficients of a layer (folded RX) are computed ONCE per layer by threads 0..n-1 into a
 // small LDS table and read back (broadcast) right before use.  Computing them inline in every thread made
 // the compiler keep all of a layer's merged gates live and spill ~1500 registers (measured: 10x slower).
@@ -88,17 +87,6 @@ __device__ __forceinline__ void set_gates(double4* gtab, F f) {
     if (threadIdx.x < N) gtab[threadIdx.x] = f((int)threadIdx.x);
     __syncthreads();
 }
-__device__ __forceinline__ double4 merge_rx(const double4& u, double2 cs) {
-    return make_double4(u.x * cs.x + u.w * cs.y, u.y * cs.x - u.z * cs.y, u.z * cs.x + u.y * cs.y, u.w * cs.x - u.x * cs.y);
-}
-// d/dtheta of U RX(theta) = (-i/2) (U X U^dagger) (U RX), and U X U^dagger = n . sigma, so the encoding gradient
-// Im<lam|X|psi> taken between RX and U equals n . (X,Y,Z) of the inner products taken after the merged gate.
-__device__ __forceinline__ void rotated_x_axis(const double4& u, double& nx, double& ny, double& nz) {
-    nx = u.x * u.x - u.y * u.y - u.z * u.z + u.w * u.w;
-    ny = -2.0 * (u.x * u.y - u.z * u.w);
-    nz = 2.0 * (u.x * u.z + u.y * u.w);
-}
-
 // Im<l|sigma|p> contributions of one pair (p0,p1),(l0,l1)
 __device__ __forceinline__ void inner(const c2& p0, const c2& p1, const c2& l0, const c2& l1, double& X, double& Y,
                                       double& Z) {
