@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 N_QUBITS, NET, B_IN, T_IN, BATCH = 5, (40, 2, 20, 2), 100, 2, 1024
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # AMD MI355X spec, FP64 vector = half of the guide's 157.3 TF FP32 vector rate
 
 
 def circuit_counts(n, net):
@@ -35,7 +36,10 @@ def circuit_counts(n, net):
     R = E + 3 * n * blk                 # rotation gates
     G = R + n * blk                     # + CNOTs
     S = 16 * (1 << n)                   # bytes of one fp64 complex state
-    return dict(E=E, blk=blk, R=R, G=G, S=S,
+    pairs = (1 << n) // 2               # amplitude pairs one gate touches
+    fma_fwd = n * blk * pairs * 16 + E * pairs * 8            # fused SU(2): 16 FMA per pair, RX: 8
+    fma_bwd = 2 * fma_fwd + n * blk * pairs * 12 + E * pairs * 4   # adjoint gates on psi and lambda + X,Y,Z / X inner products
+    return dict(E=E, blk=blk, R=R, G=G, S=S, flops_fwd=2 * fma_fwd, flops_train=2 * (fma_fwd + fma_bwd),
                 bytes_fwd=2 * S * G + S,                 # gate-streaming model, BASELINE.md section 2
                 bytes_bwd=S * (4 * G + 2 * R),           # reverse sweep on psi and lambda + <lam|.|psi> passes
                 bytes_train=S * (6 * G + 2 * R) + S)
@@ -199,6 +203,14 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "launch_ms": lg_ms, "algorithmic_bytes_per_launch": cc['bytes_train'] * BATCH,
                 "fwd_kernel_ms": fwd_ms, "fwd_achieved": cc['bytes_fwd'] * BATCH / (fwd_ms * 1e-3) / 1e9,
+                "fp64_vector": {"achieved": cc['flops_train'] * BATCH / (lg_ms * 1e-3) / 1e12,
+                                "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": cc['flops_train'] * BATCH / (lg_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                "flops_per_launch": cc['flops_train'] * BATCH,
+                                "note": "executed fp64 arithmetic of the same launch (fused SU(2) 16 FMA and RX 8 FMA "
+                                        "per amplitude pair, adjoint on psi and lambda, inner products) against the "
+                                        "fp64 vector peak: the second, honest ceiling for a 32-amplitude state whose "
+                                        "every 2x2 update needs a cross-lane exchange"},
                 "note": "achieved = gate-streaming algorithmic bytes (BASELINE.md section 2: S(6G+2R)+S per sample x 1024 "
                         "samples per launch) / HIP-event duration of the kernel alone; the state is wave-resident, so the "
                         "measured HBM traffic (PMC, bytes per launch) is inputs+outputs only and frac exceeds 1; the real "
