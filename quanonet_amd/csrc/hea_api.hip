@@ -167,17 +167,13 @@ bool use_pair(int n, int64_t B) {
     return 2 * ((B + spw - 1) / spw) <= simd_count();
 }
 
-// Workgroup-resident kernels (hea_lds.hip) for n >= 10.  Measured, 12 sub-layers, B = 1024, forward / forward+backward:
-//   n = 10: 67 / 232 us vs 124 / 321 us wave-resident;  n = 11: 110 / 450 vs 180 / 1200 us (the wave-resident
-//   backward spills);  n = 12: 205 / 880 us vs 790 us / 14.5 ms.
+// Workgroup-resident kernels (hea_lds.hip) for n >= 10; the wave-resident ones are built for n <= 9 only.
+// Measured when both existed, 12 sub-layers, B = 1024, forward / forward+backward:
+//   n = 10: 67 / 232 us vs 97 / 263 us wave-resident;  n = 11: 110 / 450 vs 144 / 1250 us (the wave-resident
+//   backward spills);  n = 12: 205 / 880 us vs 367 us / 12.4 ms.
 bool use_lds(int n, bool backward) {
-    if (!lds_supported(n)) return false;
-    if (const char* e = getenv("QHEA_LDS_KERNEL")) {           // test hook: "force" / "off"
-        if (e[0] == 'f') return true;
-        if (e[0] == 'o') return false;
-    }
     (void)backward;
-    return n >= 10;
+    return lds_supported(n);
 }
 
 Layout make_layout(int n, const Shape& sh, int64_t B) {

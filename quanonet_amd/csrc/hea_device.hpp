@@ -1233,7 +1233,7 @@ struct BwdArgs {
 #ifdef QHEA_SUBSET      // development builds: -D'QHEA_SUBSET(X)=X(2) X(5)' links only those qubit counts
 #define QHEA_FOR_EACH_N(X) QHEA_SUBSET(X)
 #else
-#define QHEA_FOR_EACH_N(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#define QHEA_FOR_EACH_N(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9)      /* n = 10..12: hea_lds.hip */
 #endif
 #define QHEA_DECLARE(NN)                                              \
     void launch_fwd_##NN(dim3 grid, hipStream_t st, const FwdArgs& a); \

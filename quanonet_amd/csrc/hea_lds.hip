@@ -1,7 +1,7 @@
 // hea_lds.hip -- workgroup-resident variant of the HEA simulator for the largest qubit counts (n = 10..12).
 //
-// The wave-resident kernels (hea_device.hpp) keep 2^(n-6) amplitudes per lane in VGPRs; with psi and lambda
-// live that exceeds the 256 architectural VGPRs for n >= 11 (backward) / n = 12 (forward) and the compiler
+// The wave-resident kernels (hea_device.hpp, built for n <= 9) keep 2^(n-6) amplitudes per lane in VGPRs; with psi
+// and lambda live that exceeds the 256 architectural VGPRs for n >= 11 (backward) / n = 12 (forward) and the compiler
 // spills to scratch.  Here ONE workgroup of 2^(n-4) threads owns one sample; the state(s) rest in LDS
 // (n = 12: 64 KB per state, psi + lambda = 128 of the CU's 160 KB) and every thread works on 16 amplitudes
 // at a time in registers:

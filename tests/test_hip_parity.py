@@ -80,32 +80,9 @@ def test_every_qubit_count_against_oracle(dev, n, backward_variant):
 
 
 @pytest.mark.parametrize('n', [10, 11, 12])
-def test_wave_resident_kernels_for_large_n(dev, n, monkeypatch):
-    """n >= 10 defaults to hea_lds.hip; the wave-resident kernels stay built for those n and must stay right."""
-    monkeypatch.setenv('QHEA_LDS_KERNEL', 'off')
-    rng = np.random.default_rng(400 + n)
-    cfgs = [(n, 2), (n + 2, 1)]
-    E, blk = O.circuit_sizes(n, cfgs)
-    B = 5
-    x = rng.uniform(-np.pi, np.pi, (B, E))
-    w = rng.uniform(-np.pi, np.pi, (blk, 3, n))
-    g = rng.normal(size=B)
-    off, co = O.ham_params(n, -3.0, 7.0)
-    ro, rst = C.hea_forward(n, cfgs, x, w, off, co, return_state=True)
-    _, rgx, rgw = C.hea_backward(n, cfgs, x, w, g, off, co)
-    for use_state in (True, False):
-        out, st, gx, gw, out2 = _run(n, cfgs, x, w, g, dev, off, co, use_state=use_state)
-        np.testing.assert_allclose(out, ro, rtol=0, atol=TOL)
-        np.testing.assert_allclose(st, rst, rtol=0, atol=TOL)
-        np.testing.assert_allclose(gx, rgx, rtol=0, atol=TOL)
-        np.testing.assert_allclose(gw, rgw, rtol=0, atol=TOL)
-
-
-@pytest.mark.parametrize('n', [10, 11, 12])
-def test_lds_resident_kernels_against_oracle(dev, n, monkeypatch):
-    """hea_lds.hip (selected automatically for n = 12) forced on for every qubit count it is built for;
-    ragged encodings (more and fewer than n per block) and a block without sub-layers included."""
-    monkeypatch.setenv('QHEA_LDS_KERNEL', 'force')
+def test_lds_resident_kernels_against_oracle(dev, n):
+    """hea_lds.hip (the kernels for n >= 10): ragged encodings (more and fewer than n per block), a block without
+    sub-layers and one without encodings included."""
     rng = np.random.default_rng(300 + n)
     cfgs = [(n, 2), (n - 3, 1), (n + 3, 2), (n, 0), (0, 1)]
     E, blk = O.circuit_sizes(n, cfgs)
@@ -166,7 +143,7 @@ def test_pauli_xy_readout(dev, n, pauli, backward_variant):
 
 
 @pytest.mark.parametrize('pauli', ['X', 'Y'])
-def test_pauli_xy_lds_kernels_and_model_path(dev, pauli, monkeypatch):
+def test_pauli_xy_lds_kernels_and_model_path(dev, pauli):
     from quanonet_amd.models import QuanONetPT
     from quanonet_amd.solver import DataParallelTrainer
     from quanonet_amd import _lib
@@ -189,8 +166,7 @@ def test_pauli_xy_lds_kernels_and_model_path(dev, pauli, monkeypatch):
     auto = DataParallelTrainer(model, lr=1e-3, fused=False)
     flat2 = auto.loss_and_grad(_t(br, dev), _t(tr, dev), _t(y, dev).unsqueeze(-1))
     np.testing.assert_allclose(flat.cpu().numpy(), flat2.cpu().numpy(), rtol=0, atol=TOL)
-    # LDS-resident kernels forced on
-    monkeypatch.setenv('QHEA_LDS_KERNEL', 'force')
+    # workgroup-resident kernels (n >= 10)
     n, cfgs = 10, [(10, 2), (13, 1)]
     E, blk = O.circuit_sizes(n, cfgs)
     x = rng.uniform(-3, 3, (4, E)); w = rng.uniform(-3, 3, (blk, 3, n)); g = rng.normal(size=4)
