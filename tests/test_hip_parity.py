@@ -102,6 +102,38 @@ def test_lds_resident_kernels_against_oracle(dev, n):
         np.testing.assert_allclose(gw, rgw, rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize('n', list(range(2, 13)))
+def test_random_block_shapes(dev, n, backward_variant):
+    """Seeded random block lists: encodings per block from {0, 1, n-1, n, n+1, 2n+1} (none, ragged, exactly the
+    wires, more than one RX layer), 0..3 sub-layers, ragged batches.  Exercises the RX fold of the n >= 6 kernels
+    (folded / not folded / folded + extra RX layers / blocks without sub-layers) against the gate-by-gate oracle."""
+    if n > 5 and backward_variant == 'pair':
+        pytest.skip("wave-pair kernel exists for n <= 5 only")
+    rng = np.random.default_rng(9000 + n)
+    for trial in range(4):
+        nb = int(rng.integers(1, 6))
+        cfgs = [(int(rng.choice([0, 1, n - 1, n, n + 1, 2 * n + 1])), int(rng.integers(0, 4))) for _ in range(nb)]
+        E, blk = O.circuit_sizes(n, cfgs)
+        if E == 0 and blk == 0:
+            cfgs.append((n, 1))
+            E, blk = O.circuit_sizes(n, cfgs)
+        B = int(rng.integers(1, 10))
+        x = rng.uniform(-np.pi, np.pi, (B, E))
+        w = rng.uniform(-np.pi, np.pi, (blk, 3, n))
+        g = rng.normal(size=B)
+        off, co = O.ham_params(n, -1.0, 3.0)
+        ro, rst = C.hea_forward(n, cfgs, x, w, off, co, return_state=True)
+        _, rgx, rgw = C.hea_backward(n, cfgs, x, w, g, off, co)
+        for use_state in (True, False):
+            out, st, gx, gw, out2 = _run(n, cfgs, x, w, g, dev, off, co, use_state=use_state)
+            msg = f"n={n} cfgs={cfgs} B={B} use_state={use_state}"
+            np.testing.assert_allclose(out, ro, rtol=0, atol=TOL, err_msg=msg)
+            np.testing.assert_allclose(out2, ro, rtol=0, atol=TOL, err_msg=msg)
+            np.testing.assert_allclose(st, rst, rtol=0, atol=TOL, err_msg=msg)
+            np.testing.assert_allclose(gx, rgx, rtol=0, atol=TOL, err_msg=msg)
+            np.testing.assert_allclose(gw, rgw, rtol=0, atol=TOL, err_msg=msg)
+
+
 def test_ham_diag_readout(dev):
     n, cfgs = 4, [(4, 1), (4, 2)]
     rng = np.random.default_rng(7)
