@@ -459,13 +459,11 @@ template <int N>
 int launch_fwd_n(long B, hipStream_t st, const FwdArgs& a) {
     using L = LCfg<N>;
     constexpr size_t smem = L::STATE_BYTES + L::SCRATCH_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lds_fwd_kernel<N>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return QHEA_ELAUNCH;
-        attr_done = true;
-    }
+    // every launch (microseconds against a millisecond kernel): the attribute is per device, and a process may
+    // drive more than one
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(lds_fwd_kernel<N>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return QHEA_ELAUNCH;
     hipLaunchKernelGGL(lds_fwd_kernel<N>, dim3((unsigned)B), dim3(L::T), smem, st, a.runs, a.B, a.E, a.cs, a.gates,
                        a.off, a.co, a.diag, a.pauli, a.out, a.state_out, a.bias);
     return QHEA_OK;
@@ -475,13 +473,9 @@ template <int N>
 int launch_bwd_n(long B, hipStream_t st, const BwdArgs& a) {
     using L = LCfg<N>;
     constexpr size_t smem = 2 * L::STATE_BYTES + L::SCRATCH_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lds_bwd_kernel<N>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return QHEA_ELAUNCH;
-        attr_done = true;
-    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(lds_bwd_kernel<N>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return QHEA_ELAUNCH;
     hipLaunchKernelGGL(lds_bwd_kernel<N>, dim3((unsigned)B), dim3(L::T), smem, st, a.runs, a.B, a.E, a.blk, a.cs,
                        a.gates, a.off, a.co, a.diag, a.pauli, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out, a.grad_x,
                        a.partial);
