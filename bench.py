@@ -192,13 +192,14 @@ def main():
         if pm:
             try:
                 t = json.load(open(pm[-1]))
-                key = [k for k in t if 'bwd_pair_kernel<5>' in k] or [k for k in t if 'bwd_kernel<5>' in k]
+                key = ([k for k in t if 'bwd_tri_kernel<5>' in k] or [k for k in t if 'bwd_pair_kernel<5>' in k]
+                       or [k for k in t if 'bwd_kernel<5>' in k])
                 traffic = float(t[key[0]]['hbm_bytes_corrected'])
                 traffic_src = os.path.relpath(pm[-1], ROOT)
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "qhea::bwd_pair_kernel<5> (fused forward + MSE residual + adjoint reverse sweep, psi-wave/lambda-wave "
-                          "pipeline; qhea::bwd_kernel<5> when the batch fills the SIMDs)",
+        roof = {"bound": "hbm", "kernel": "qhea::bwd_tri_kernel<5> (fused forward + MSE residual + adjoint reverse sweep as a psi-chain / "
+                          "lambda-chain / sigma-wave pipeline; qhea::bwd_kernel<5> when the batch fills the SIMDs)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "launch_ms": lg_ms, "algorithmic_bytes_per_launch": cc['bytes_train'] * BATCH,

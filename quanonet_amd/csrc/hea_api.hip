@@ -143,8 +143,8 @@ struct Layout {
     bool lds_fwd, lds_bwd, pair;
 };
 
-// Wave-pair pipelined backward kernel (n <= 5): two waves per sample group, so it pays while the packed kernel
-// would leave at least half of the SIMDs without a wave (hea_device.hpp: bwd_pair_kernel)
+// Pipelined backward kernels (n <= 5): several waves per sample group (psi chain, lambda chain, sigma waves), so they
+// pay while the packed kernel would leave SIMDs without a wave (hea_device.hpp: bwd_tri_kernel, bwd_pair_kernel)
 int simd_count() {
     static int cached = 0;
     if (cached == 0) {
@@ -157,14 +157,23 @@ int simd_count() {
     }
     return cached;
 }
+int use_tri() {                                   // which pipelined variant when use_pair() says "pipelined"
+    if (const char* e = getenv("QHEA_BACKWARD_KERNEL")) {     // test hook: "pair" forces the two-wave pipeline
+        if (e[0] == 'p' && e[1] == 'a' && e[2] == 'i') return 0;
+    }
+    return 1;                                     // psi / lambda / sigma waves (bwd_tri_kernel): 148 vs 170 us at cfg 2
+}
 bool use_pair(int n, int64_t B) {
     if (n > 5 || B <= 0) return false;
     if (const char* e = getenv("QHEA_BACKWARD_KERNEL")) {     // test hook: "packed" / "pair" force a variant
         if (e[0] == 'p' && e[1] == 'a' && e[2] == 'c') return false;
         if (e[0] == 'p' && e[1] == 'a' && e[2] == 'i') return true;
+        if (e[0] == 't') return true;
     }
+    // measured at n = 5 (us per backward call incl. prep/reduce; packed / pipelined): B = 1024 194 / 155, B = 1536
+    // 247 / 181, B = 2048 260 / 273 -- pipelined while the sample groups fill at most 3/4 of the SIMDs
     const int spw = 64 >> n;
-    return 2 * ((B + spw - 1) / spw) <= simd_count();
+    return 4 * ((B + spw - 1) / spw) <= 3 * (int64_t)simd_count();
 }
 
 // Workgroup-resident kernels (hea_lds.hip) for n >= 10; the wave-resident ones are built for n <= 9 only.
@@ -557,7 +566,7 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
     const int gates_bytes = (int)((sh.blk + 2) * n_qubits * kGateBytes);
     double* partial = reinterpret_cast<double*>(ws + L.off_part);
     const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, g,
-                     state_in, nullptr, nullptr, 0.0, out, grad_x, partial, ham_pauli};
+                     state_in, nullptr, nullptr, 0.0, out, grad_x, partial, ham_pauli, use_tri()};
     profile_begin(st);
     if (L.lds_bwd) {
         if (launch_lds_bwd(n_qubits, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;
@@ -648,7 +657,7 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const doubl
                      reinterpret_cast<const double2*>(ws + M.L.off_cs), ws + M.L.off_U,
                      (int)((mi.sh.blk + 2) * mi.n * kGateBytes), desc->ham_offset, desc->ham_coeff, ham_diag,
                      nullptr, nullptr, y, mi.has_bias ? params + mi.off_bias : nullptr, inv_batch_total,
-                     pr, gx, partial, desc->ham_pauli};
+                     pr, gx, partial, desc->ham_pauli, use_tri()};
     profile_begin(st);
     if (M.L.lds_bwd) {
         if (launch_lds_bwd(mi.n, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;

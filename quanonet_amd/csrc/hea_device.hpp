@@ -1218,6 +1218,255 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
 }
 
 // ---------------------------------------------------------------------------------------
+// psi / lambda / sigma pipelined backward kernel (n <= 5, small batches) -- the default for them
+// ---------------------------------------------------------------------------------------
+// Cycle counters in the wave-pair kernel showed that its lambda wave is the critical path and that a chain step
+// (ring^-1, n adjoint gates) is LATENCY-bound: ~85 dependent instructions in ~1000-1400 cycles, the wave issues
+// less than a quarter of the time.  What the lambda wave does besides its chain -- the inner products against psi
+// and the cross-lane gradient sums -- neither belongs to that dependency chain nor needs to wait for it.  So here a
+// workgroup is 2 + kSigmaWaves waves:
+//   wave 0 (psi):    as in the pair kernel -- forward sweep, then walks psi backwards and publishes it after every
+//                    ring^-1 / at every RX phase;
+//   wave 1 (lambda): forms lambda_N, walks lambda backwards and publishes it at the same points -- nothing else;
+//   waves 2.. (sigma): step t belongs to sigma wave t % kSigmaWaves: it reads psi (own amplitude + n partners) and
+//                    lambda (own amplitude) of that step from the two LDS rings, takes the inner products and sums
+//                    them over the wave with the REGISTER butterfly (no LDS: the LDS pipe is what the two chains'
+//                    exchanges, gate reads and publishes wait on; LDS-staged sums here cost +5 us).
+// With 2 sigma waves a 1024-sample batch puts two waves on every SIMD (one chain-type, one sigma-type on average);
+// 1 sigma wave: 157 us, 2: 148 us, 3: 155 us, 4: 167 us per launch (pair kernel: 170 us).  A variant in which the two
+// chain waves share the sigma work by step parity (no extra waves) ran at 225 us: sigma work inside a chain wave
+// delays every later chain step.  Hand-off as in the pair kernel: monotonic LDS counters, cached reads, bounded spins.
+constexpr int kSigmaWaves = 2;        // sigma waves per workgroup: step t belongs to sigma wave t % kSigmaWaves
+struct TriSync {
+    int psi_prod, lam_prod, ready, abort;
+    int cursor[kSigmaWaves];          // every step below cursor[w] has been read by sigma wave w or is not its
+};
+
+template <int N>
+__global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs runs, long B, int E, int blk,
+                                                      const double2* __restrict__ cs,
+                                                      const char* __restrict__ gates, int gates_bytes,
+                                                      double off, double co,
+                                                      const double* __restrict__ diag, int pauli,
+                                                      const double* __restrict__ g,
+                                                      const double* __restrict__ state_in,
+                                                      const double* __restrict__ y,
+                                                      const double* __restrict__ bias,
+                                                      double inv_bt,
+                                                      double* __restrict__ out,
+                                                      double* __restrict__ grad_x,
+                                                      double* __restrict__ partial) {
+    using C = Cfg<N>;
+    static_assert(C::R == 1 && C::LDSRED, "three-wave kernel: all-lane layout, n <= 5");
+    __shared__ double2 cs_lds[2 * kCsPerWave + 16];
+    __shared__ __attribute__((aligned(16))) char gate_ring[2 * kRingBytesPerWave];
+    __shared__ double2 psi_ring[kPairRing][64];
+    __shared__ double2 lam_ring[kPairRing][64];
+    __shared__ double2 psi_final[64];
+    __shared__ TriSync sync;
+
+    const int lane = threadIdx.x & 63;
+    const int role = threadIdx.x >> 6;                  // 0: psi, 1: lambda, 2: sigma
+    const long wave = blockIdx.x;                       // one sample group per workgroup
+    const long b_raw = wave * C::SPW + (lane >> C::LB);
+    const bool valid = b_raw < B;
+    const long b = valid ? b_raw : B - 1;
+    const int klow = lane & (C::LANES - 1);
+
+    if (threadIdx.x == 0) {
+        sync.psi_prod = 0; sync.lam_prod = 0; sync.ready = 0; sync.abort = 0;
+        for (int w = 0; w < kSigmaWaves; ++w) sync.cursor[w] = w;
+    }
+    __syncthreads();
+
+    if (role < 2) {
+        // ------------------------------------------------------------------ psi / lambda chains
+        const int ring_fwd = ring_source<N>(lane, false);
+        const int ring_rev = ring_source<N>(lane, true);
+        CsStream<N> csx;
+        csx.init(cs_lds + role * kCsPerWave, cs, b, E, lane, lane >> C::LB);
+        GateStream<N> gs;
+        gs.init(gates, gates_bytes, gate_ring + role * kRingBytesPerWave, lane);
+        double sr[1], si[1];                            // this wave's state: psi or lambda
+        bool ok = true;
+        int seen[kSigmaWaves];
+#pragma unroll
+        for (int w = 0; w < kSigmaWaves; ++w) seen[w] = 0;
+        if (role == 0) {
+            if (state_in) {
+                const double2 a = reinterpret_cast<const double2*>(state_in)[(b << N) + klow];
+                sr[0] = a.x; si[0] = a.y;
+            } else {
+                forward_sweep<N>(sr, si, runs, csx, gs, lane, ring_fwd);
+            }
+            psi_final[lane] = make_double2(sr[0], si[0]);
+            __hip_atomic_store(&sync.ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            int seen_ready = 0;
+            ok = pair_wait_ge(&sync.ready, 1, &sync.abort, seen_ready);
+            double fr[1] = {psi_final[lane].x}, fi[1] = {psi_final[lane].y};
+            basis_change<N, false>(fr, fi, pauli, lane);
+            const double h = ham_weight<N>(klow, off, co, diag);
+            double gb;
+            {
+                double v[1] = {h * (fr[0] * fr[0] + fi[0] * fi[0])};
+                lane_reduce<1, C::LB>(v, lane);
+                const double pred = v[0] + (bias ? bias[0] : 0.0);
+                if (out && valid && klow == 0) out[b] = pred;
+                gb = y ? 2.0 * (pred - y[b]) * inv_bt : g[b];
+            }
+            if (!valid) gb = 0.0;
+            sr[0] = gb * h * fr[0]; si[0] = gb * h * fi[0];
+            basis_change<N, true>(sr, si, pauli, lane);
+        }
+        double2 (*ring)[64] = role == 0 ? psi_ring : lam_ring;
+        int* prod = role == 0 ? &sync.psi_prod : &sync.lam_prod;
+        int col = E, step = 0;
+#ifdef QHEA_TRI_TIMING
+        long tm_wait = 0, tm_pub = 0; const long tm0 = clock64();
+#endif
+        auto publish = [&]() {
+#ifdef QHEA_TRI_TIMING
+            const long c0 = clock64();
+#endif
+            if (step >= kPairRing) {
+#pragma unroll
+                for (int w = 0; w < kSigmaWaves; ++w)
+                    ok = ok && pair_wait_ge(&sync.cursor[w], step - kPairRing + 1, &sync.abort, seen[w]);
+            }
+#ifdef QHEA_TRI_TIMING
+            const long c1 = clock64(); tm_wait += c1 - c0;
+#endif
+            ring[step % kPairRing][lane] = make_double2(sr[0], si[0]);
+            ++step;
+            // LDS executes one wave's instructions in issue order, so the counter cannot overtake the data: a
+            // compiler-only fence instead of the s_waitcnt that a workgroup-scope release store costs (1 us per launch)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __hip_atomic_store(prod, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef QHEA_TRI_TIMING
+            tm_pub += clock64() - c1;
+#endif
+        };
+        gs.template prime<false>(blk - 1);
+        for (int ri = runs.nruns - 1; ri >= 0 && ok; --ri) {
+            const int ne = runs.enc[ri], nld = runs.ld[ri];
+            const int nchunks = (ne + N - 1) / N;
+            for (int rep = 0; rep < runs.count[ri] && ok; ++rep) {
+                if (ne > 0) csx.template prefetch<false>(col - (ne - (nchunks - 1) * N));
+                for (int l = nld - 1; l >= 0; --l) {
+                    apply_ring<N, true>(sr, si, lane, ring_rev);
+                    publish();                                           // state after this sub-layer's gates
+                    gs.template begin<false>();
+                    static_rfor<0, N>([&](auto q) {
+                        constexpr int Q = decltype(q)::value;
+                        const double4 u = gs.template cur<false, Q>();
+                        apply_su2<N, Q>(sr, si, u.x, -u.y, -u.z, -u.w);
+                        gs.template done<false, Q>();
+                    });
+                    gs.template advance<false>();
+                }
+                col -= ne;
+                if (ne > 0) {
+                    publish();                                           // state after this block's RX phase
+                    for (int ch = nchunks - 1; ch >= 0; --ch) {
+                        const int j0 = ch * N;
+                        const int m = (ne - j0) < N ? (ne - j0) : N;
+                        if (ch != nchunks - 1) csx.template prefetch<false>(col + j0);
+                        static_rfor<0, N>([&](auto q) {
+                            constexpr int Q = decltype(q)::value;
+                            if (Q < m) apply_rx<N, Q>(sr, si, csx.nxt[Q].x, -csx.nxt[Q].y);
+                        });
+                    }
+                }
+            }
+        }
+#ifdef QHEA_TRI_TIMING
+        if (blockIdx.x == 7 && lane == 0)
+            printf("chain role %d steps %d: reverse %ld wait %ld pub %ld\n", role, step, clock64() - tm0, tm_wait, tm_pub);
+#endif
+    } else {
+        // ------------------------------------------------------------------ sigma wave: inner products + sums
+        double* __restrict__ part_w = partial + wave * (long)blk * C::KW;
+        const int me = role - 2;                        // this sigma wave takes the steps with step % kSigmaWaves == me
+#ifdef QHEA_TRI_TIMING
+        long tm_swait = 0; const long tm0 = clock64();
+#define TMS(x) x
+#else
+#define TMS(x)
+#endif
+        int seen_p = 0, seen_l = 0;
+        bool ok = true;
+        int col = E, sub = blk, step = 0;
+        for (int ri = runs.nruns - 1; ri >= 0 && ok; --ri) {
+            const int ne = runs.enc[ri], nld = runs.ld[ri];
+            const int nchunks = (ne + N - 1) / N;
+            for (int rep = 0; rep < runs.count[ri] && ok; ++rep) {
+                for (int l = nld - 1; l >= 0; --l) {
+                    --sub;
+                    if (step % kSigmaWaves != me) { ++step; continue; }
+                    TMS(const long c0 = clock64();)
+                    ok = ok && pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
+                    ok = ok && pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
+                    TMS(tm_swait += clock64() - c0;)
+                    const double2* slot = psi_ring[step % kPairRing];
+                    const double2 p = slot[lane];
+                    double2 qv[N];
+                    static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
+                    const double2 lm = lam_ring[step % kPairRing][lane];
+                    __hip_atomic_store(&sync.cursor[me], step + kSigmaWaves, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ++step;
+                    double acc3[C::KW];
+#pragma unroll
+                    for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
+                    static_for<0, N>([&](auto q) {
+                        constexpr int Q = decltype(q)::value;
+                        const double s = ((lane >> Q) & 1) ? -1.0 : 1.0;
+                        acc3[3 * Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
+                        acc3[3 * Q + 1] = -s * (lm.x * qv[Q].x + lm.y * qv[Q].y);
+                        acc3[3 * Q + 2] = s * (lm.x * p.y - lm.y * p.x);
+                    });
+                    lane_reduce<C::KW, 6>(acc3, lane);                   // registers only: the LDS pipe stays with the chains
+                    if (lane < C::KW) part_w[(long)sub * C::KW + lane] = acc3[0];
+                }
+                col -= ne;
+                if (ne > 0 && step % kSigmaWaves != me) {
+                    ++step;
+                } else if (ne > 0) {
+                    ok = ok && pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
+                    ok = ok && pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
+                    const double2* slot = psi_ring[step % kPairRing];
+                    double2 qv[N];
+                    static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
+                    const double2 lm = lam_ring[step % kPairRing][lane];
+                    __hip_atomic_store(&sync.cursor[me], step + kSigmaWaves, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ++step;
+                    double gx[C::KX];
+#pragma unroll
+                    for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
+                    static_for<0, N>([&](auto q) {                       // every RX of the phase commutes with X_q
+                        constexpr int Q = decltype(q)::value;
+                        if (Q < ne) gx[Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
+                    });
+                    for (int ch = nchunks - 1; ch >= 0; --ch) {
+                        const int j0 = ch * N;
+                        const int m = (ne - j0) < N ? (ne - j0) : N;
+                        double gc[C::KX];                                // wires repeat across chunks with equal gradients
+#pragma unroll
+                        for (int i = 0; i < C::KX; ++i) gc[i] = gx[i];
+                        store_grad_x<N>(gc, lane, wave, B, E, grad_x, col + j0, m);
+                    }
+                }
+            }
+        }
+#ifdef QHEA_TRI_TIMING
+        if (blockIdx.x == 7 && lane == 0)
+            printf("sigma %d: total %ld wait(sublayer steps) %ld\n", me, clock64() - tm0, tm_swait);
+#endif
+#undef TMS
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // launch entry points; one translation unit per qubit count (hea_inst.hip, -DQHEA_N=n)
 // ---------------------------------------------------------------------------------------
 struct FwdArgs {
@@ -1228,6 +1477,7 @@ struct BwdArgs {
     Runs runs; long B; int E; int blk; const double2* cs; const char* gates; int gates_bytes; double off, co;
     const double* diag; const double* g; const double* state_in; const double* y; const double* bias; double inv_bt;
     double* out; double* grad_x; double* partial; int pauli;
+    int tri;                  // n <= 5 small-batch backward: 0 = psi/lambda pair, 1 = three waves, 2 = balanced pair
 };
 
 #ifdef QHEA_SUBSET      // development builds: -D'QHEA_SUBSET(X)=X(2) X(5)' links only those qubit counts

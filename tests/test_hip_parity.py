@@ -36,10 +36,10 @@ def _run(n, cfgs, x, w, g, dev, off, co, diag=None, use_state=True, pauli='Z'):
     return (out.cpu().numpy(), st.cpu().numpy(), gx.cpu().numpy(), gw.cpu().numpy(), out2.cpu().numpy())
 
 
-@pytest.fixture(params=['packed', 'pair'])
+@pytest.fixture(params=['packed', 'pair', 'tri'])
 def backward_variant(request, monkeypatch):
-    """Both backward kernels for n <= 5 (one wave per sample group vs the psi-wave / lambda-wave pipeline);
-    the library reads the variable at every call."""
+    """The three backward kernels for n <= 5 (one wave per sample group, the psi-wave / lambda-wave pipeline, the
+    psi / lambda / sigma three-wave pipeline); the library reads the variable at every call."""
     monkeypatch.setenv('QHEA_BACKWARD_KERNEL', request.param)
     return request.param
 
@@ -58,8 +58,8 @@ def test_golden_vectors(dev, backward_variant):
 
 @pytest.mark.parametrize('n', list(range(2, 13)))
 def test_every_qubit_count_against_oracle(dev, n, backward_variant):
-    if n > 5 and backward_variant == 'pair':
-        pytest.skip("wave-pair kernel exists for n <= 5 only")
+    if n > 5 and backward_variant != 'packed':
+        pytest.skip("the pipelined kernels exist for n <= 5 only")
     rng = np.random.default_rng(100 + n)
     cfgs = [(n, 2), (n, 1), (n, 2)]
     E, blk = O.circuit_sizes(n, cfgs)
@@ -107,8 +107,8 @@ def test_random_block_shapes(dev, n, backward_variant):
     """Seeded random block lists: encodings per block from {0, 1, n-1, n, n+1, 2n+1} (none, ragged, exactly the
     wires, more than one RX layer), 0..3 sub-layers, ragged batches.  Exercises the RX fold of the n >= 6 kernels
     (folded / not folded / folded + extra RX layers / blocks without sub-layers) against the gate-by-gate oracle."""
-    if n > 5 and backward_variant == 'pair':
-        pytest.skip("wave-pair kernel exists for n <= 5 only")
+    if n > 5 and backward_variant != 'packed':
+        pytest.skip("the pipelined kernels exist for n <= 5 only")
     rng = np.random.default_rng(9000 + n)
     for trial in range(4):
         nb = int(rng.integers(1, 6))
@@ -153,8 +153,8 @@ def test_pauli_xy_readout(dev, n, pauli, backward_variant):
     """H = offset + coeff * sum_i P_i for P = X, Y (generate_simple_hamiltonian's `pauli`,
     core/quantum_circuits_ms.py:28-39).  The oracle applies the Paulis one by one; the kernels rotate the
     measurement basis.  state_out stays psi_N (before that rotation)."""
-    if n > 5 and backward_variant == 'pair':
-        pytest.skip("wave-pair kernel exists for n <= 5 only")
+    if n > 5 and backward_variant != 'packed':
+        pytest.skip("the pipelined kernels exist for n <= 5 only")
     rng = np.random.default_rng(500 + n)
     cfgs = [(n, 2), (n + 1, 1)]
     E, blk = O.circuit_sizes(n, cfgs)
