@@ -437,7 +437,9 @@ __device__ __forceinline__ void basis_change(double (&re)[Cfg<N>::R], double (&i
 // no RX phase and no extra inner products for the folded chunk.  For n <= 5 a wave carries several samples: the ring
 // would need a table copy per sample, the fold's three dependent LDS round trips cost more than the five cheap
 // one-register RX gates they replace (measured at n = 5: forward 58.8 vs 54 us), and the per-sample X,Y,Z sums the
-// reverse trick needs are the expensive ones -- so those kernels keep the separate RX phase.
+// reverse trick needs are the expensive ones -- so those kernels keep the separate RX phase.  (Merging per lane in
+// registers instead, 8 multiply-adds per gate off the dependency chain, was also tried at n = 5: forward 62.0 vs
+// 61.9 us -- the RX applications it replaces cost as many instructions, and the sweep is mostly issue-bound.)
 template <int N>
 constexpr bool kFold = Cfg<N>::SPW == 1;
 __device__ __forceinline__ double4 merge_rx(const double4& u, const double2& cs) {
@@ -1281,6 +1283,8 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
 
     if (role < 2) {
         // ------------------------------------------------------------------ psi / lambda chains
+        __builtin_amdgcn_s_setprio(3);                  // the chains are the critical path, the sigma wave sharing the
+                                                        // SIMD fills their gaps (measured: 148.0 vs 155.1 us per call)
         const int ring_fwd = ring_source<N>(lane, false);
         const int ring_rev = ring_source<N>(lane, true);
         CsStream<N> csx;
