@@ -193,6 +193,21 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Single-device training step: qhea_model_loss_grad followed by qhea_adam_step on the same flat vectors, with the
+ * Adam update applied by the very thread of the reduce kernel that finishes each gradient -- three launches
+ * (prep, circuit, reduce+Adam) for `pred = model(...); loss = MSE(pred, y); loss.backward(); optimizer.step()`
+ * (solvers/solver_pt.py:232-236).  Bitwise the same parameters as the two separate calls.  Data-parallel runs
+ * keep the two calls, with the gradient all-reduce between them.  grad still receives [gradients | sse | sum y^2].
+ */
+int qhea_model_train_step(const qhea_model_desc* desc, int64_t batch,
+                          const double* branch, const double* trunk, const double* y /*DEVICE [B]*/,
+                          double* params /*DEVICE flat, updated in place*/, const double* ham_diag,
+                          double inv_batch_total, double* grad /*DEVICE [P+2]*/, double* pred /*DEVICE [B] or NULL*/,
+                          double* exp_avg /*DEVICE [P]*/, double* exp_avg_sq /*DEVICE [P]*/, int64_t step,
+                          double lr, double beta1, double beta2, double eps, double weight_decay,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * One Adam update of the flat parameter vector, in place, in ONE launch.  Same arithmetic as
  * torch.optim.Adam (amsgrad=False, maximize=False; the reference's optimizer, solvers/solver_pt.py:149-163):
  *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)

@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get('QHEA_LIB') or os.path.join(_HERE, 'libquanonet_hea.so
 
 EXPORTS = ['qhea_version', 'qhea_strerror', 'qhea_device_count', 'qhea_workspace_bytes',
            'qhea_forward', 'qhea_backward', 'qhea_model_param_count', 'qhea_model_workspace_bytes',
-           'qhea_model_forward', 'qhea_model_loss_grad', 'qhea_profile_next_circuit_kernel', 'qhea_adam_step']
+           'qhea_model_forward', 'qhea_model_loss_grad', 'qhea_model_train_step', 'qhea_profile_next_circuit_kernel',
+           'qhea_adam_step']
 
 
 class ModelDesc(ctypes.Structure):
@@ -27,7 +28,7 @@ class ModelDesc(ctypes.Structure):
 
 
 MODEL_QUANONET, MODEL_HEAQNN = 0, 1
-MIN_LIB_VERSION = 200           # 0.2.0: qhea_forward/backward take ham_pauli
+MIN_LIB_VERSION = 300           # 0.3.0: qhea_model_train_step (0.2.0: qhea_forward/backward take ham_pauli)
 PAULI = {'Z': 0, 'X': 1, 'Y': 2}
 
 
@@ -91,6 +92,10 @@ def load():
     lib.qhea_model_loss_grad.restype = ctypes.c_int
     lib.qhea_model_loss_grad.argtypes = [mdp, ctypes.c_int64, dp, dp, dp, dp, dp, ctypes.c_double, dp, dp,
                                          vp, ctypes.c_size_t, vp]
+    lib.qhea_model_train_step.restype = ctypes.c_int
+    lib.qhea_model_train_step.argtypes = [mdp, ctypes.c_int64, dp, dp, dp, dp, dp, ctypes.c_double, dp, dp, dp, dp,
+                                          ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                          ctypes.c_double, ctypes.c_double, vp, ctypes.c_size_t, vp]
     _lib = lib
     return lib
 
@@ -252,6 +257,35 @@ def model_loss_grad(desc, branch, trunk, y, params, inv_batch_total, grad, ham_d
                                       _ptr(ham_diag), float(inv_batch_total), _ptr(grad), _ptr(pred),
                                       _ptr(ws), ws.numel(), _stream(branch.device))
     _check(rc, 'qhea_model_loss_grad')
+    return grad
+
+
+def model_train_step(desc, branch, trunk, y, params, inv_batch_total, grad, exp_avg, exp_avg_sq, step, lr, beta1,
+                     beta2, eps, weight_decay, ham_diag=None, pred=None):
+    """Single-device step: loss + gradients + Adam update of `params` in three launches; returns grad."""
+    lib = load()
+    B = branch.shape[0]
+    _dev_f64(branch, 'branch', (B, desc.branch_in))
+    if desc.model == MODEL_QUANONET:
+        _dev_f64(trunk, 'trunk', (B, desc.trunk_in))
+    _dev_f64(y, 'y')
+    if y.numel() != B:
+        raise QheaError(f"y has {y.numel()} elements, expected {B}")
+    for t, nm in ((params, 'params'), (grad, 'grad'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
+        _dev_f64(t, nm)
+    if not (exp_avg.numel() == exp_avg_sq.numel() == params.numel() and grad.numel() == params.numel() + 2):
+        raise QheaError("model_train_step: flat vectors have inconsistent lengths")
+    _dev_f64(ham_diag, 'ham_diag', (1 << desc.n_qubits,))
+    _dev_f64(pred, 'pred', (B,))
+    nbytes = int(lib.qhea_model_workspace_bytes(ctypes.byref(desc), B))
+    ws = _workspace(branch.device, nbytes)
+    with torch.cuda.device(branch.device):
+        rc = lib.qhea_model_train_step(ctypes.byref(desc), B, _ptr(branch), _ptr(trunk), _ptr(y), _ptr(params),
+                                       _ptr(ham_diag), float(inv_batch_total), _ptr(grad), _ptr(pred),
+                                       _ptr(exp_avg), _ptr(exp_avg_sq), int(step), float(lr), float(beta1),
+                                       float(beta2), float(eps), float(weight_decay), _ptr(ws), ws.numel(),
+                                       _stream(branch.device))
+    _check(rc, 'qhea_model_train_step')
     return grad
 
 

@@ -64,11 +64,28 @@ __device__ __forceinline__ double slice_sum(const double* __restrict__ p, long r
     return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
+// One Adam update (torch.optim.Adam arithmetic) of element i.  Shared by adam_kernel and by the reduce kernel of
+// qhea_model_train_step, where the thread that finishes a gradient applies it at once.
+struct AdamArgs {
+    double* p; double* m; double* v;           // p == nullptr: no update (plain qhea_model_loss_grad)
+    double lr_over_bc1, inv_sqrt_bc2, b1, b2, eps, wd;
+};
+__device__ __forceinline__ void adam_update(const AdamArgs& a, long i, double gi) {
+    const double pi = a.p[i];
+    if (a.wd != 0.0) gi += a.wd * pi;
+    const double mi = a.b1 * a.m[i] + (1.0 - a.b1) * gi;         // torch: exp_avg.lerp_(grad, 1 - beta1)
+    const double vi = a.b2 * a.v[i] + (1.0 - a.b2) * gi * gi;    //        exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    a.m[i] = mi; a.v[i] = vi;
+    const double denom = sqrt(vi) * a.inv_sqrt_bc2 + a.eps;
+    a.p[i] = pi - a.lr_over_bc1 * (mi / denom);
+}
+
 // grad_w[s,{0,1,2},q] from the per-wave (X,Y,Z) partial sums (column sums over waves of partial[wave][s][kw]).
 //   g_c = Y;  g_b = cos(c) Z + sin(c) X;  g_a = cos(b) Y - sin(b) cos(c) X + sin(b) sin(c) Z
 __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw, long nwaves,
-                                                 const double* __restrict__ partial, const double* __restrict__ w,
-                                                 double* __restrict__ grad_w, double* acc /*[kRedThreads]*/) {
+                                                 const double* __restrict__ partial, const double* w /* may alias adam->p */,
+                                                 double* __restrict__ grad_w, double* acc /*[kRedThreads]*/,
+                                                 const AdamArgs* adam = nullptr, long adam_base = 0) {
     const int cols = red_cols(kw), nslices = kRedThreads / cols;
     const int j = threadIdx.x % cols, slice = threadIdx.x / cols;
     const long ncols = (long)blk * kw;
@@ -91,9 +108,16 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
             sincos(ws[n + q], &sb, &cb);
             sincos(ws[2 * n + q], &sc, &cc);
             double* gs = grad_w + (long)s * 3 * n;
-            gs[2 * n + q] = Y;
-            gs[n + q] = cc * Z + sc * X;
-            gs[q] = cb * Y - sb * cc * X + sb * sc * Z;
+            const double gc = Y, gb = cc * Z + sc * X, ga = cb * Y - sb * cc * X + sb * sc * Z;
+            gs[2 * n + q] = gc;
+            gs[n + q] = gb;
+            gs[q] = ga;
+            if (adam && adam->p) {               // this thread alone reads and writes the three angles of gate (s, q)
+                const long base = adam_base + (long)s * 3 * n;
+                adam_update(*adam, base + 2 * n + q, gc);
+                adam_update(*adam, base + n + q, gb);
+                adam_update(*adam, base + q, ga);
+            }
         }
     }
 }
@@ -204,19 +228,9 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     return L;
 }
 
-__global__ void adam_kernel(long n, double* __restrict__ p, const double* __restrict__ g, double* __restrict__ m,
-                            double* __restrict__ v, double lr_over_bc1, double inv_sqrt_bc2, double b1, double b2,
-                            double eps, double wd) {
+__global__ void adam_kernel(long n, const double* __restrict__ g, AdamArgs a) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double gi = g[i];
-    const double pi = p[i];
-    if (wd != 0.0) gi += wd * pi;
-    const double mi = b1 * m[i] + (1.0 - b1) * gi;           // torch: exp_avg.lerp_(grad, 1 - beta1)
-    const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;      //        exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    m[i] = mi; v[i] = vi;
-    const double denom = sqrt(vi) * inv_sqrt_bc2 + eps;
-    p[i] = pi - lr_over_bc1 * (mi / denom);
+    if (i < n) adam_update(a, i, g[i]);
 }
 
 thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
@@ -294,14 +308,15 @@ struct GradMap {                // where each gradient lives in the flat output
 // sse, sum y^2.
 constexpr int kFreqCols = 16, kFreqSlices = kRedThreads / kFreqCols;
 __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
-        int n, int blk, int kw, long nwaves, const double* __restrict__ partial, const double* __restrict__ w,
+        int n, int blk, int kw, long nwaves, const double* __restrict__ partial, const double* w,
         long B, int E, EncDesc enc, const double* __restrict__ grad_x, const double* __restrict__ pred,
-        const double* __restrict__ y, double inv_bt, GradMap gm, int nb_w, int nb_x, double* __restrict__ grad) {
+        const double* __restrict__ y, double inv_bt, GradMap gm, int nb_w, int nb_x, double* __restrict__ grad,
+        AdamArgs adam) {
     __shared__ double acc[kRedThreads];
     __shared__ double acc2[kRedThreads];
     const int bid = blockIdx.x;
     if (bid < nb_w) {
-        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc);
+        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, &adam, gm.off_ans);
     } else if (bid < nb_w + nb_x) {
         const int j = threadIdx.x % kFreqCols, slice = threadIdx.x / kFreqCols;
         const int e = (bid - nb_w) * kFreqCols + j;
@@ -337,6 +352,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
             for (int i = 0; i < kFreqSlices; ++i) { t0 += acc[i * kFreqCols + j]; t1 += acc2[i * kFreqCols + j]; }
             grad[gm.off_b[si] + ee] = t0;
             grad[gm.off_w[si] + ee] = t1;
+            if (adam.p) { adam_update(adam, gm.off_b[si] + ee, t0); adam_update(adam, gm.off_w[si] + ee, t1); }
         }
     } else {
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -358,7 +374,11 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         if (threadIdx.x == 0) {
             grad[gm.off_sse] = acc[0];
             grad[gm.off_sse + 1] = red3[0];
-            if (gm.off_bias >= 0) grad[gm.off_bias] = 2.0 * inv_bt * acc2[0];
+            if (gm.off_bias >= 0) {
+                const double gbias = 2.0 * inv_bt * acc2[0];
+                grad[gm.off_bias] = gbias;
+                if (adam.p) adam_update(adam, gm.off_bias, gbias);
+            }
         }
     }
 }
@@ -471,7 +491,7 @@ using namespace qhea;
 
 extern "C" {
 
-int qhea_version(void) { return 200; }
+int qhea_version(void) { return 300; }
 
 const char* qhea_strerror(int code) {
     switch (code) {
@@ -631,9 +651,10 @@ int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double*
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 
-int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
-                         const double* y, const double* params, const double* ham_diag, double inv_batch_total,
-                         double* grad, double* pred, void* workspace, size_t workspace_bytes, void* stream) {
+static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
+                                const double* y, const double* params, const double* ham_diag, double inv_batch_total,
+                                double* grad, double* pred, void* workspace, size_t workspace_bytes, void* stream,
+                                const AdamArgs& adam) {
     ModelInfo mi;
     int rc = model_info(desc, mi);
     if (rc != QHEA_OK) return rc;
@@ -677,8 +698,27 @@ int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const doubl
     const int nb_x = mi.trainable ? (int)((mi.sh.E + kFreqCols - 1) / kFreqCols) : 0;
     hipLaunchKernelGGL(reduce_model_kernel, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
                        (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
-                       gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad);
+                       gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam);
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+}
+
+int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
+                         const double* y, const double* params, const double* ham_diag, double inv_batch_total,
+                         double* grad, double* pred, void* workspace, size_t workspace_bytes, void* stream) {
+    return model_loss_grad_impl(desc, batch, branch, trunk, y, params, ham_diag, inv_batch_total, grad, pred, workspace,
+                                workspace_bytes, stream, AdamArgs{});
+}
+
+int qhea_model_train_step(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
+                          const double* y, double* params, const double* ham_diag, double inv_batch_total,
+                          double* grad, double* pred, double* exp_avg, double* exp_avg_sq, int64_t step, double lr,
+                          double beta1, double beta2, double eps, double weight_decay, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    if (step < 1 || !params || !exp_avg || !exp_avg_sq || batch <= 0) return QHEA_EINVAL;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const AdamArgs adam{params, exp_avg, exp_avg_sq, lr / bc1, 1.0 / sqrt(bc2), beta1, beta2, eps, weight_decay};
+    return model_loss_grad_impl(desc, batch, branch, trunk, y, params, ham_diag, inv_batch_total, grad, pred, workspace,
+                                workspace_bytes, stream, adam);
 }
 
 int qhea_adam_step(int64_t n, double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t step,
@@ -687,9 +727,9 @@ int qhea_adam_step(int64_t n, double* params, const double* grads, double* exp_a
     if (n == 0) return QHEA_OK;
     if (!params || !grads || !exp_avg || !exp_avg_sq) return QHEA_EINVAL;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const AdamArgs adam{params, exp_avg, exp_avg_sq, lr / bc1, 1.0 / sqrt(bc2), beta1, beta2, eps, weight_decay};
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       (long)n, params, grads, exp_avg, exp_avg_sq, lr / bc1, 1.0 / sqrt(bc2), beta1, beta2, eps,
-                       weight_decay);
+                       (long)n, grads, adam);
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 

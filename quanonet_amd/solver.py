@@ -151,6 +151,18 @@ class DataParallelTrainer:
 
     def train_step(self, *batch, global_batch=None):
         """batch = (branch, trunk, y) or (x, y): this rank's shard.  Returns the flat buffer (device)."""
+        if self.world == 1 and self.desc is not None and isinstance(self.optimizer, FlatAdam):
+            # single device: loss, gradients and the Adam update in three launches (qhea_model_train_step)
+            from . import _lib
+            *inputs, y = batch
+            gb = float(global_batch if global_batch is not None else y.shape[0])
+            opt, g = self.optimizer, self.optimizer.param_groups[0]
+            opt.t += 1
+            _lib.model_train_step(self.desc, inputs[0], inputs[1] if len(inputs) > 1 else None, y.reshape(-1),
+                                  self.pflat, 1.0 / gb, self.flat, opt.exp_avg, opt.exp_avg_sq, opt.t, g['lr'],
+                                  g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'],
+                                  ham_diag=self._ham_diag())
+            return self.flat
         self.loss_and_grad(*batch, global_batch=global_batch)
         if self.world > 1:
             self.dist.all_reduce(self.flat)            # SUM; one latency-bound message (19 KB at Q5)

@@ -437,6 +437,40 @@ def test_flat_adam_equals_torch_adam(dev):
     assert sd['flat_state']['step'] == 25
 
 
+@pytest.mark.parametrize('kind', ['quanonet', 'quanonet_fixed_freq', 'heaqnn'])
+def test_fused_train_step_is_bitwise_the_two_call_path(dev, kind):
+    """qhea_model_train_step (Adam applied inside the reduce kernel) == qhea_model_loss_grad + qhea_adam_step."""
+    from quanonet_amd.models import QuanONetPT, HEAQNNPT
+    from quanonet_amd.solver import DataParallelTrainer
+    rng = np.random.default_rng(77)
+    B = 53
+
+    def make():
+        torch.manual_seed(5)
+        if kind == 'heaqnn':
+            return HEAQNNPT(4, 6, (3, 2), scale_coeff=0.2, if_trainable_freq=True).to(dev)
+        return QuanONetPT(5, 7, 2, (3, 2, 2, 1), scale_coeff=0.1, if_trainable_freq=(kind == 'quanonet')).to(dev)
+
+    if kind == 'heaqnn':
+        data = [(_t(rng.normal(size=(B, 6)), dev), _t(rng.normal(size=B), dev)) for _ in range(6)]
+    else:
+        data = [(_t(rng.normal(size=(B, 7)), dev), _t(rng.uniform(size=(B, 2)), dev), _t(rng.normal(size=B), dev))
+                for _ in range(6)]
+    fused = DataParallelTrainer(make(), lr=3e-3, optimizer_kwargs={'weight_decay': 0.01})
+    split = DataParallelTrainer(make(), lr=3e-3, optimizer_kwargs={'weight_decay': 0.01})
+    assert torch.equal(fused.pflat, split.pflat)
+    for batch in data:
+        f1 = fused.train_step(*batch).clone()                       # world == 1 -> qhea_model_train_step
+        split.loss_and_grad(*batch)
+        f2 = split.flat.clone()
+        split.optimizer.step()
+        assert torch.equal(f1, f2)
+        assert torch.equal(fused.pflat, split.pflat)
+    assert torch.equal(fused.optimizer.exp_avg, split.optimizer.exp_avg)
+    assert torch.equal(fused.optimizer.exp_avg_sq, split.optimizer.exp_avg_sq)
+    assert fused.optimizer.t == split.optimizer.t == len(data)
+
+
 def test_float32_module_like_the_reference(dev):
     """The reference keeps float32 parameters/inputs (solver_pt.py:132); the op computes in fp64 and casts back."""
     from quanonet_amd.models import QuanONetPT
