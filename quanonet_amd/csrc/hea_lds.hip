@@ -3,13 +3,13 @@
 // The wave-resident kernels (hea_device.hpp, built for n <= 9) keep 2^(n-6) amplitudes per lane in VGPRs; with psi
 // and lambda live that exceeds the 256 architectural VGPRs for n >= 11 (backward) / n = 12 (forward) and the compiler
 // spills to scratch.  Here ONE workgroup of 2^(n-4) threads owns one sample; the state(s) rest in LDS
-// (n = 12: 64 KB per state, psi + lambda = 128 of the CU's 160 KB) and every thread works on 16 amplitudes
-// at a time in registers:
+// (n = 12: 64 KB per state, psi + lambda = 128 of the CU's 160 KB) and every thread works on 16 (forward) or 8
+// (backward) amplitudes at a time in registers:
 //
-//   * a gate layer (the n fused SU(2) gates of a sub-layer) is ceil(n/4) passes; pass p loads, per thread,
-//     the 16 amplitudes that differ in index bits A..A+3 (A = 4p, or n-4 for a ragged last pass), applies the
-//     gates of those qubits as in-register 2x2 updates and stores them back -- one LDS round trip of the
-//     state per FOUR gates;
+//   * a gate layer (the n fused SU(2) gates of a sub-layer) is ceil(n/LG) passes, LG = 4 or 3; pass p loads, per
+//     thread, the 2^LG amplitudes that differ in index bits A..A+LG-1 (A = LG p, or n-LG for a ragged last pass),
+//     applies the gates of those qubits as in-register 2x2 updates and stores them back -- one LDS round trip
+//     of the state per LG gates;
 //   * a block's RX encodings are folded, per sample, into the fused gates of its first sub-layer
 //     (U RX(theta) is again an SU(2) matrix), so they cost no layer of their own; their gradient is
 //     n . (X,Y,Z) of that sub-layer's inner products with n = axis of U X U^dagger (rotated_x_axis);
@@ -18,9 +18,8 @@
 //     its own: the last pass of a forward sub-layer scatters its amplitudes to ring(k), the first pass of a
 //     reverse sub-layer gathers from ring(k); per amplitude that is ONE xor with a compile-time constant
 //     on top of a per-thread base computed once per kernel;
-//   * LDS index swizzle phys(k) = k ^ ((k >> 4) & 15): for every pass the 16-byte accesses of 16
-//     neighbouring lanes fall into 16 different bank quads (a thread's 16 amplitudes would otherwise sit
-//     256 B apart for A = 0).
+//   * LDS index swizzle (phys): for every pass the 16-byte accesses of 16 neighbouring lanes fall into 16
+//     different bank quads (a thread's 16 amplitudes would otherwise sit 256 B apart for A = 0).
 //
 // Same circuit, same fused SU(2) table, same adjoint recipe (X,Y,Z inner products taken after the fused gate,
 // mapped to the three angles in reduce_kernel) as the wave-resident kernels.  Bound by fp64 FMA issue
@@ -36,34 +35,53 @@ namespace {
 
 struct c2 { double x, y; };
 
-template <int N>
+constexpr int kFwdLG = 4;      // gate qubits per pass (see LCfg): forward kernel
+#ifndef QHEA_LDS_BWD_LG
+#define QHEA_LDS_BWD_LG 3
+#endif
+constexpr int kBwdLG = QHEA_LDS_BWD_LG;      // backward kernel
+
+// LG = log2(amplitudes a thread holds per pass) = gate qubits per pass.  Forward kernel: 4 (256 threads at n = 12,
+// two workgroups per CU).  Backward kernel: 3 (512 threads at n = 12, 248 VGPRs): psi + lambda fill the LDS, so one
+// workgroup per CU, and the larger workgroup gives two waves per SIMD at the price of a fourth pass per layer --
+// measured the two cancel almost exactly (forward + backward, LG = 3 / 4: n = 10 193 / 200 us, n = 11 410 / 415 us
+// per 12 sub-layers, cfg 5 8.46 / 8.47 ms), LG = 3 kept.
+template <int N, int LG>
 struct LCfg {
     static_assert(N >= 10 && N <= 12, "workgroup-resident kernels: n = 10..12");
-    static constexpr int T = 1 << (N - 4);            // threads per sample; 16 amplitudes each
+    static_assert(LG == 3 || LG == 4, "3 or 4 gate qubits per pass");
+    static constexpr int M = 1 << LG;                 // amplitudes per thread and pass
+    static constexpr int T = 1 << (N - LG);           // threads per sample
     static constexpr int NW = T / 64;                 // waves
-    static constexpr int NP = (N + 3) / 4;            // passes per gate layer
+    static constexpr int NP = (N + LG - 1) / LG;      // passes per gate layer
     static constexpr int DIM = 1 << N;
     static constexpr int KW = Cfg<N>::KW;             // padded 3n = row width of `partial` (reduce_kernel)
     static constexpr size_t STATE_BYTES = (size_t)16 << N;
     static constexpr size_t SCRATCH_BYTES = (size_t)NW * 64 * sizeof(double) + 16 * sizeof(double4);   // sums + gate table
 };
-template <int N, int P>
+template <int N, int P, int LG>
 struct Pass {
-    static constexpr int Q0 = 4 * P;                                   // gate qubits [Q0, Q1)
-    static constexpr int Q1 = (4 * P + 4 < N) ? 4 * P + 4 : N;
-    static constexpr int A = (4 * P + 4 <= N) ? 4 * P : N - 4;         // lowest of the four index bits held per thread
+    static constexpr int Q0 = LG * P;                                  // gate qubits [Q0, Q1)
+    static constexpr int Q1 = (LG * P + LG < N) ? LG * P + LG : N;
+    static constexpr int A = (LG * P + LG <= N) ? LG * P : N - LG;     // lowest of the LG index bits held per thread
 };
 
-__host__ __device__ constexpr int phys(int k) { return k ^ ((k >> 4) & 15); }     // involution (bits 4..7 stay)
+// LDS index swizzle (an involution, linear over GF(2)): whatever the pass, the 16-byte accesses of 16 neighbouring
+// lanes fall into 16 different bank quads.  LG = 4: bits 0..3 ^= bits 4..7.  LG = 3 (passes at bits 0, 3, 6, 9 or a
+// ragged last one): bits 0..2 ^= bits 4..6 and bit 3 ^= bit 6.
+template <int LG>
+__host__ __device__ constexpr int phys(int k) {
+    return LG == 4 ? (k ^ ((k >> 4) & 15)) : (k ^ ((k >> 4) & 7) ^ (((k >> 6) & 1) << 3));
+}
 // CNOT ring as a map of basis indices: |k> -> |ring(k)>, CNOT(control (i+1)%n, target i) for i = 0..n-1 in order
 template <int N>
 __host__ __device__ constexpr int ring_dst(int k) {
     for (int i = 0; i < N; ++i) k ^= ((k >> ((i + 1) % N)) & 1) << i;
     return k;
 }
-// index bits of thread t for a pass with base bit A (the four bits A..A+3 are the per-thread local index j)
-template <int A>
-__device__ __forceinline__ int thread_part(int t) { return ((t >> A) << (A + 4)) | (t & ((1 << A) - 1)); }
+// index bits of thread t for a pass with base bit A (the LG bits A..A+LG-1 are the per-thread local index j)
+template <int A, int LG>
+__device__ __forceinline__ int thread_part(int t) { return ((t >> A) << (A + LG)) | (t & ((1 << A) - 1)); }
 
 // [[a,b],[-conj b, conj a]] on (p0,p1); u = (ar, ai, br, bi)
 __device__ __forceinline__ void su2(c2& p0, c2& p1, const double4& u) {
@@ -98,67 +116,67 @@ __device__ __forceinline__ void inner_x(const c2& p0, const c2& p1, const c2& l0
     X += (l0.x * p1.y - l0.y * p1.x) + (l1.x * p0.y - l1.y * p0.x);
 }
 
-// the 16 amplitudes of this thread for a pass with base bit A: local index j <-> index bits A..A+3.
+// the 2^LG amplitudes of this thread for a pass with base bit A: local index j <-> index bits A..A+LG-1.
 // `base` = phys(thread_part) (in place) or phys(ring(thread_part)) (through the ring); both maps are linear
 // over GF(2), so amplitude j sits at base ^ constant_j.
-template <int N, int A, bool RING>
-__device__ __forceinline__ void load16(const double2* s, int base, c2 (&v)[16]) {
-    static_for<0, 16>([&](auto jj) {
+template <int N, int A, bool RING, int LG>
+__device__ __forceinline__ void load_group(const double2* s, int base, c2 (&v)[1 << LG]) {
+    static_for<0, (1 << LG)>([&](auto jj) {
         constexpr int J = decltype(jj)::value;
-        constexpr int CJ = RING ? phys(ring_dst<N>(J << A)) : phys(J << A);
+        constexpr int CJ = RING ? phys<LG>(ring_dst<N>(J << A)) : phys<LG>(J << A);
         const double2 a = s[base ^ CJ];
         v[J].x = a.x; v[J].y = a.y;
     });
 }
-template <int N, int A, bool RING>
-__device__ __forceinline__ void store16(double2* s, int base, const c2 (&v)[16]) {
-    static_for<0, 16>([&](auto jj) {
+template <int N, int A, bool RING, int LG>
+__device__ __forceinline__ void store_group(double2* s, int base, const c2 (&v)[1 << LG]) {
+    static_for<0, (1 << LG)>([&](auto jj) {
         constexpr int J = decltype(jj)::value;
-        constexpr int CJ = RING ? phys(ring_dst<N>(J << A)) : phys(J << A);
+        constexpr int CJ = RING ? phys<LG>(ring_dst<N>(J << A)) : phys<LG>(J << A);
         s[base ^ CJ] = make_double2(v[J].x, v[J].y);
     });
 }
-template <int LBIT>
-__device__ __forceinline__ void apply16(c2 (&v)[16], const double4& u) {
-    static_for<0, 16>([&](auto jj) {
+template <int LBIT, int LG>
+__device__ __forceinline__ void apply_group(c2 (&v)[1 << LG], const double4& u) {
+    static_for<0, (1 << LG)>([&](auto jj) {
         constexpr int J = decltype(jj)::value;
         if constexpr (!(J & (1 << LBIT))) su2(v[J], v[J | (1 << LBIT)], u);
     });
 }
 
-template <int N>
+template <int N, int LG>
 struct Bases {                        // per-thread LDS index bases, computed once per kernel
-    int plain[LCfg<N>::NP];           // phys(thread_part<A_p>(t))
+    int plain[LCfg<N, LG>::NP];       // phys(thread_part<A_p>(t))
     int ring;                         // phys(ring(thread_part<A_last>(t)))
     __device__ __forceinline__ void init(int t) {
-        static_for<0, LCfg<N>::NP>([&](auto p) {
+        static_for<0, LCfg<N, LG>::NP>([&](auto p) {
             constexpr int P = decltype(p)::value;
-            plain[P] = phys(thread_part<Pass<N, P>::A>(t));
+            plain[P] = phys<LG>(thread_part<Pass<N, P, LG>::A, LG>(t));
         });
-        ring = phys(ring_dst<N>(thread_part<Pass<N, LCfg<N>::NP - 1>::A>(t)));
+        ring = phys<LG>(ring_dst<N>(thread_part<Pass<N, LCfg<N, LG>::NP - 1, LG>::A, LG>(t)));
     }
 };
 
 // One forward gate layer.  gate(q, u) fills u and returns whether qubit q has a gate (wave-uniform).
 // RING: the last pass scatters through the CNOT ring.
-template <int N, bool RING, class G>
-__device__ __forceinline__ void fwd_layer(double2* s, const Bases<N>& bs, G gate) {
-    constexpr int NP = LCfg<N>::NP;
+template <int N, int LG, bool RING, class G>
+__device__ __forceinline__ void fwd_layer(double2* s, const Bases<N, LG>& bs, G gate) {
+    constexpr int NP = LCfg<N, LG>::NP;
     static_for<0, NP>([&](auto p) {
         constexpr int P = decltype(p)::value;
-        using PS = Pass<N, P>;
-        c2 v[16];
-        load16<N, PS::A, false>(s, bs.plain[P], v);
+        using PS = Pass<N, P, LG>;
+        c2 v[1 << LG];
+        load_group<N, PS::A, false, LG>(s, bs.plain[P], v);
         static_for<PS::Q0, PS::Q1>([&](auto q) {
             constexpr int Q = decltype(q)::value;
             double4 u;
-            if (gate(Q, u)) apply16<Q - PS::A>(v, u);
+            if (gate(Q, u)) apply_group<Q - PS::A, LG>(v, u);
         });
         if constexpr (RING && P == NP - 1) {
             __syncthreads();                               // every thread holds its amplitudes: safe to permute
-            store16<N, PS::A, true>(s, bs.ring, v);
+            store_group<N, PS::A, true, LG>(s, bs.ring, v);
         } else {
-            store16<N, PS::A, false>(s, bs.plain[P], v);
+            store_group<N, PS::A, false, LG>(s, bs.plain[P], v);
         }
         __syncthreads();
     });
@@ -167,27 +185,27 @@ __device__ __forceinline__ void fwd_layer(double2* s, const Bases<N>& bs, G gate
 // One reverse layer on psi and lambda: (ring^-1 via a gather in the first pass when RING), then per qubit the
 // inner products Im<lam|sigma|psi> (XYZ: all three, else X only) followed by the adjoint gate on both states.
 // gate(q, u) returns the ADJOINT coefficients.  acc: XYZ ? [3q..3q+2] : [q].
-template <int N, bool RING, bool XYZ, class G, int NA>
-__device__ __forceinline__ void bwd_layer(double2* psi, double2* lam, const Bases<N>& bs, G gate, double (&acc)[NA]) {
-    constexpr int NP = LCfg<N>::NP;
+template <int N, int LG, bool RING, bool XYZ, class G, int NA>
+__device__ __forceinline__ void bwd_layer(double2* psi, double2* lam, const Bases<N, LG>& bs, G gate, double (&acc)[NA]) {
+    constexpr int NP = LCfg<N, LG>::NP;
     static_rfor<0, NP>([&](auto p) {
         constexpr int P = decltype(p)::value;
-        using PS = Pass<N, P>;
-        c2 v[16], l[16];
+        using PS = Pass<N, P, LG>;
+        c2 v[1 << LG], l[1 << LG];
         if constexpr (RING && P == NP - 1) {
-            load16<N, PS::A, true>(psi, bs.ring, v);
-            load16<N, PS::A, true>(lam, bs.ring, l);
+            load_group<N, PS::A, true, LG>(psi, bs.ring, v);
+            load_group<N, PS::A, true, LG>(lam, bs.ring, l);
             __syncthreads();                               // all gathers done before anything is overwritten
         } else {
-            load16<N, PS::A, false>(psi, bs.plain[P], v);
-            load16<N, PS::A, false>(lam, bs.plain[P], l);
+            load_group<N, PS::A, false, LG>(psi, bs.plain[P], v);
+            load_group<N, PS::A, false, LG>(lam, bs.plain[P], l);
         }
         static_for<PS::Q0, PS::Q1>([&](auto q) {
             constexpr int Q = decltype(q)::value;
             constexpr int LBIT = Q - PS::A;
             double4 u;
             if (gate(Q, u)) {
-                static_for<0, 16>([&](auto jj) {
+                static_for<0, (1 << LG)>([&](auto jj) {
                     constexpr int J = decltype(jj)::value;
                     if constexpr (!(J & (1 << LBIT))) {
                         constexpr int J1 = J | (1 << LBIT);
@@ -199,8 +217,8 @@ __device__ __forceinline__ void bwd_layer(double2* psi, double2* lam, const Base
                 });
             }
         });
-        store16<N, PS::A, false>(psi, bs.plain[P], v);
-        store16<N, PS::A, false>(lam, bs.plain[P], l);
+        store_group<N, PS::A, false, LG>(psi, bs.plain[P], v);
+        store_group<N, PS::A, false, LG>(lam, bs.plain[P], l);
         __syncthreads();
     });
 }
@@ -215,36 +233,36 @@ __device__ __forceinline__ double ham_w(int k, double off, double co, const doub
 }
 
 // sum of one double per thread over the workgroup (fixed order), result in every thread
-template <int N>
+template <int N, int LG>
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
     double t[1] = {v};
     lane_reduce<1, 6>(t, threadIdx.x & 63);
-    if constexpr (LCfg<N>::NW == 1) return t[0];
+    if constexpr (LCfg<N, LG>::NW == 1) return t[0];
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = t[0];
     __syncthreads();
     double tot = scratch[0];
 #pragma unroll
-    for (int w = 1; w < LCfg<N>::NW; ++w) tot += scratch[w];
+    for (int w = 1; w < LCfg<N, LG>::NW; ++w) tot += scratch[w];
     __syncthreads();                                       // scratch is reused by the caller
     return tot;
 }
 
 // readout-basis change on every qubit (see basis_change in hea_device.hpp): X -> RY(-pi/2), Y -> RX(+pi/2)
-template <int N>
-__device__ __forceinline__ void basis_lds(double2* s, const Bases<N>& bs, int pauli, bool dag) {
+template <int N, int LG>
+__device__ __forceinline__ void basis_lds(double2* s, const Bases<N, LG>& bs, int pauli, bool dag) {
     if (pauli == 0) return;
     const double r = 0.70710678118654752440, sr = dag ? -r : r;
     const double4 uc = pauli == 1 ? make_double4(r, 0.0, sr, 0.0) : make_double4(r, 0.0, 0.0, -sr);
-    fwd_layer<N, false>(s, bs, [&](int, double4& u) { u = uc; return true; });
+    fwd_layer<N, LG, false>(s, bs, [&](int, double4& u) { u = uc; return true; });
 }
 
-template <int N>
-__device__ __forceinline__ void forward_lds(double2* psi, double4* gtab, const Bases<N>& bs, const Runs& runs,
+template <int N, int LG>
+__device__ __forceinline__ void forward_lds(double2* psi, double4* gtab, const Bases<N, LG>& bs, const Runs& runs,
                                             const double2* __restrict__ cs_b, const char* __restrict__ gates) {
-    using L = LCfg<N>;
+    using L = LCfg<N, LG>;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < L::M; ++j) {
         const int p = threadIdx.x + j * L::T;
         psi[p] = make_double2(p == 0 ? 1.0 : 0.0, 0.0);              // |0..0>: phys(0) = 0
     }
@@ -260,7 +278,7 @@ __device__ __forceinline__ void forward_lds(double2* psi, double4* gtab, const B
                 const int j0 = ch * N;
                 const int m = (ne - j0) < N ? (ne - j0) : N;
                 const double2* c = cs_b + col + j0;
-                fwd_layer<N, false>(psi, bs, [&](int q, double4& u) {
+                fwd_layer<N, LG, false>(psi, bs, [&](int q, double4& u) {
                     if (q >= m) return false;
                     u = rx_su2(c[q]);
                     return true;
@@ -273,12 +291,12 @@ __device__ __forceinline__ void forward_lds(double2* psi, double4* gtab, const B
                 set_gates<N>(gtab, [&](int q) {
                     return merge_rx(gate_u(gates, N, sub, q), q < m ? c[q] : make_double2(1.0, 0.0));
                 });
-                fwd_layer<N, true>(psi, bs, [&](int q, double4& u) { u = gtab[q]; return true; });
+                fwd_layer<N, LG, true>(psi, bs, [&](int q, double4& u) { u = gtab[q]; return true; });
                 ++sub;
             }
             col += ne;
             for (int l = (nsep < nchunks) ? 1 : 0; l < nld; ++l, ++sub)
-                fwd_layer<N, true>(psi, bs, [&](int q, double4& u) { u = gate_u(gates, N, sub, q); return true; });
+                fwd_layer<N, LG, true>(psi, bs, [&](int q, double4& u) { u = gate_u(gates, N, sub, q); return true; });
         }
     }
 }
@@ -286,42 +304,43 @@ __device__ __forceinline__ void forward_lds(double2* psi, double4* gtab, const B
 }  // namespace
 
 template <int N>
-__global__ __launch_bounds__(LCfg<N>::T) void lds_fwd_kernel(Runs runs, long B, int E, const double2* __restrict__ cs,
+__global__ __launch_bounds__((LCfg<N, kFwdLG>::T)) void lds_fwd_kernel(Runs runs, long B, int E, const double2* __restrict__ cs,
                                                              const char* __restrict__ gates, double off, double co,
                                                              const double* __restrict__ diag, int pauli,
                                                              double* __restrict__ out, double* __restrict__ state_out,
                                                              const double* __restrict__ bias) {
-    using L = LCfg<N>;
+    constexpr int LG = kFwdLG;
+    using L = LCfg<N, LG>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2* psi = reinterpret_cast<double2*>(smem);
     double* scratch = reinterpret_cast<double*>(smem + L::STATE_BYTES);
     double4* gtab = reinterpret_cast<double4*>(scratch + L::NW * 64);
     const long b = blockIdx.x;
-    Bases<N> bs;
+    Bases<N, LG> bs;
     bs.init(threadIdx.x);
-    forward_lds<N>(psi, gtab, bs, runs, cs + b * E, gates);
+    forward_lds<N, LG>(psi, gtab, bs, runs, cs + b * E, gates);
     if (state_out) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < L::M; ++j) {
             const int k = threadIdx.x + j * L::T;
-            reinterpret_cast<double2*>(state_out)[(b << N) + k] = psi[phys(k)];
+            reinterpret_cast<double2*>(state_out)[(b << N) + k] = psi[phys<LG>(k)];
         }
     }
-    basis_lds<N>(psi, bs, pauli, false);
+    basis_lds<N, LG>(psi, bs, pauli, false);
     double acc = 0.0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < L::M; ++j) {
         const int k = threadIdx.x + j * L::T;
-        const double2 a = psi[phys(k)];
+        const double2 a = psi[phys<LG>(k)];
         acc += ham_w<N>(k, off, co, diag) * (a.x * a.x + a.y * a.y);
     }
-    const double tot = block_sum<N>(acc, scratch);
+    const double tot = block_sum<N, LG>(acc, scratch);
     if (threadIdx.x == 0) out[b] = tot + (bias ? bias[0] : 0.0);
 }
 
 // Backward: one row of `partial` per sample ([B][blk][KW]); grad_x written directly.
 template <int N>
-__global__ __launch_bounds__(LCfg<N>::T) void lds_bwd_kernel(Runs runs, long B, int E, int blk,
+__global__ __launch_bounds__((LCfg<N, kBwdLG>::T)) void lds_bwd_kernel(Runs runs, long B, int E, int blk,
                                                              const double2* __restrict__ cs,
                                                              const char* __restrict__ gates, double off, double co,
                                                              const double* __restrict__ diag, int pauli,
@@ -331,7 +350,8 @@ __global__ __launch_bounds__(LCfg<N>::T) void lds_bwd_kernel(Runs runs, long B, 
                                                              const double* __restrict__ bias, double inv_bt,
                                                              double* __restrict__ out, double* __restrict__ grad_x,
                                                              double* __restrict__ partial) {
-    using L = LCfg<N>;
+    constexpr int LG = kBwdLG;
+    using L = LCfg<N, LG>;
     constexpr int KW = L::KW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2* psi = reinterpret_cast<double2*>(smem);
@@ -341,40 +361,40 @@ __global__ __launch_bounds__(LCfg<N>::T) void lds_bwd_kernel(Runs runs, long B, 
     const long b = blockIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const double2* __restrict__ cs_b = cs + b * E;
-    Bases<N> bs;
+    Bases<N, LG> bs;
     bs.init(threadIdx.x);
 
     if (state_in) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < L::M; ++j) {
             const int k = threadIdx.x + j * L::T;
-            psi[phys(k)] = reinterpret_cast<const double2*>(state_in)[(b << N) + k];
+            psi[phys<LG>(k)] = reinterpret_cast<const double2*>(state_in)[(b << N) + k];
         }
         __syncthreads();
     } else {
-        forward_lds<N>(psi, gtab, bs, runs, cs_b, gates);
+        forward_lds<N, LG>(psi, gtab, bs, runs, cs_b, gates);
     }
-    basis_lds<N>(psi, bs, pauli, false);
+    basis_lds<N, LG>(psi, bs, pauli, false);
     double acc = 0.0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < L::M; ++j) {
         const int k = threadIdx.x + j * L::T;
-        const double2 a = psi[phys(k)];
+        const double2 a = psi[phys<LG>(k)];
         acc += ham_w<N>(k, off, co, diag) * (a.x * a.x + a.y * a.y);
     }
-    const double pred = block_sum<N>(acc, scratch) + (bias ? bias[0] : 0.0);
+    const double pred = block_sum<N, LG>(acc, scratch) + (bias ? bias[0] : 0.0);
     if (out && threadIdx.x == 0) out[b] = pred;
     const double gb = y ? 2.0 * (pred - y[b]) * inv_bt : g[b];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < L::M; ++j) {
         const int k = threadIdx.x + j * L::T;
-        const double2 a = psi[phys(k)];
+        const double2 a = psi[phys<LG>(k)];
         const double h = gb * ham_w<N>(k, off, co, diag);
-        lam[phys(k)] = make_double2(h * a.x, h * a.y);
+        lam[phys<LG>(k)] = make_double2(h * a.x, h * a.y);
     }
     __syncthreads();
-    basis_lds<N>(psi, bs, pauli, true);
-    basis_lds<N>(lam, bs, pauli, true);
+    basis_lds<N, LG>(psi, bs, pauli, true);
+    basis_lds<N, LG>(lam, bs, pauli, true);
 
     double* __restrict__ part_b = partial + b * (long)blk * KW;
     int col = E, sub = blk;
@@ -395,7 +415,7 @@ __global__ __launch_bounds__(LCfg<N>::T) void lds_bwd_kernel(Runs runs, long B, 
                 set_gates<N>(gtab, [&](int q) {
                     return dagger(merge_rx(gate_u(gates, N, sub, q), q < mm ? c[q] : make_double2(1.0, 0.0)));
                 });
-                bwd_layer<N, true, true>(psi, lam, bs, [&](int q, double4& u) { u = gtab[q]; return true; }, xyz);
+                bwd_layer<N, LG, true, true>(psi, lam, bs, [&](int q, double4& u) { u = gtab[q]; return true; }, xyz);
                 // workgroup sum of the 3n per-thread values: wave butterfly, then the waves through LDS
                 lane_reduce<KW, 6>(xyz, lane);               // lane i holds the wave total of value i
                 if (lane < KW) scratch[wv * 64 + lane] = xyz[0];
@@ -426,7 +446,7 @@ __global__ __launch_bounds__(LCfg<N>::T) void lds_bwd_kernel(Runs runs, long B, 
                 double gx[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) gx[i] = 0.0;
-                bwd_layer<N, false, false>(psi, lam, bs, [&](int q, double4& u) {
+                bwd_layer<N, LG, false, false>(psi, lam, bs, [&](int q, double4& u) {
                     if (q >= m) return false;
                     u = dagger(rx_su2(c[q]));
                     return true;
@@ -457,7 +477,7 @@ namespace {
 
 template <int N>
 int launch_fwd_n(long B, hipStream_t st, const FwdArgs& a) {
-    using L = LCfg<N>;
+    using L = LCfg<N, kFwdLG>;
     constexpr size_t smem = L::STATE_BYTES + L::SCRATCH_BYTES;
     // every launch (microseconds against a millisecond kernel): the attribute is per device, and a process may
     // drive more than one
@@ -471,7 +491,7 @@ int launch_fwd_n(long B, hipStream_t st, const FwdArgs& a) {
 
 template <int N>
 int launch_bwd_n(long B, hipStream_t st, const BwdArgs& a) {
-    using L = LCfg<N>;
+    using L = LCfg<N, kBwdLG>;
     constexpr size_t smem = 2 * L::STATE_BYTES + L::SCRATCH_BYTES;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(lds_bwd_kernel<N>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
