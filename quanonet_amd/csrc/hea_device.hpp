@@ -88,6 +88,19 @@ __device__ __forceinline__ void static_rfor(F&& f) {     // END-1 down to I
 // ---------------------------------------------------------------------------------------
 // cross-lane exchange with lane ^ MASK (MASK a single bit, 1..32)
 // ---------------------------------------------------------------------------------------
+// body(q) for the gate qubits q < m of an RX chunk: ONE wave-uniform test for the usual full chunk (m == n) instead
+// of a compare-and-branch per gate
+template <int N, class F>
+__device__ __forceinline__ void for_gates_below(int m, F body) {
+    if (m >= N) static_for<0, N>([&](auto q) { body(q); });
+    else static_for<0, N>([&](auto q) { if (decltype(q)::value < m) body(q); });
+}
+template <int N, class F>
+__device__ __forceinline__ void rfor_gates_below(int m, F body) {
+    if (m >= N) static_rfor<0, N>([&](auto q) { body(q); });
+    else static_rfor<0, N>([&](auto q) { if (decltype(q)::value < m) body(q); });
+}
+
 template <int MASK>
 __device__ __forceinline__ int xchg_i32(int v) {
     if constexpr (MASK == 1) {
@@ -715,9 +728,9 @@ __device__ __forceinline__ void forward_sweep(double (&re)[Cfg<N>::R], double (&
         const int m0 = ne < N ? ne : N;
         for (int rep = 0; rep < runs.count[ri]; ++rep) {
             if (!fold) {
-                static_for<0, N>([&](auto q) {
+                for_gates_below<N>(ne, [&](auto q) {
                     constexpr int Q = decltype(q)::value;
-                    if (Q < ne) apply_rx<N, Q>(re, im, csx.nxt[Q].x, csx.nxt[Q].y);
+                    apply_rx<N, Q>(re, im, csx.nxt[Q].x, csx.nxt[Q].y);
                 });
             }
             for (int j0 = N; j0 < ne; j0 += N) {          // more encodings than wires (not used by the reference)
@@ -955,13 +968,11 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
                     double gx[C::KX];
 #pragma unroll
                     for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
-                    static_rfor<0, N>([&](auto q) {
+                    rfor_gates_below<N>(ne, [&](auto q) {
                         constexpr int Q = decltype(q)::value;
-                        if (Q < ne) {
-                            gx[Q] = pauli_x_inner<N, Q>(pr, pi, lr, li);
-                            apply_rx<N, Q>(pr, pi, csx.nxt[Q].x, -csx.nxt[Q].y);
-                            apply_rx<N, Q>(lr, li, csx.nxt[Q].x, -csx.nxt[Q].y);
-                        }
+                        gx[Q] = pauli_x_inner<N, Q>(pr, pi, lr, li);
+                        apply_rx<N, Q>(pr, pi, csx.nxt[Q].x, -csx.nxt[Q].y);
+                        apply_rx<N, Q>(lr, li, csx.nxt[Q].x, -csx.nxt[Q].y);
                     });
                     if constexpr (C::LDSRED) sums.put_x(gx, col, ne);
                     else store_grad_x<N>(gx, lane, wave, B, E, grad_x, col, ne);
@@ -1117,9 +1128,9 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
                         const int j0 = ch * N;
                         const int m = (ne - j0) < N ? (ne - j0) : N;
                         if (ch != nchunks - 1) csx.template prefetch<false>(col + j0);
-                        static_rfor<0, N>([&](auto q) {
+                        rfor_gates_below<N>(m, [&](auto q) {
                             constexpr int Q = decltype(q)::value;
-                            if (Q < m) apply_rx<N, Q>(pr, pi, csx.nxt[Q].x, -csx.nxt[Q].y);
+                            apply_rx<N, Q>(pr, pi, csx.nxt[Q].x, -csx.nxt[Q].y);
                         });
                     }
                 }
@@ -1197,17 +1208,17 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
                     double gx[C::KX];
 #pragma unroll
                     for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
-                    static_for<0, N>([&](auto q) {                       // every RX of the phase commutes with X_q
+                    for_gates_below<N>(ne, [&](auto q) {                 // every RX of the phase commutes with X_q
                         constexpr int Q = decltype(q)::value;
-                        if (Q < ne) gx[Q] = lr[0] * qv[Q].y - li[0] * qv[Q].x;
+                        gx[Q] = lr[0] * qv[Q].y - li[0] * qv[Q].x;
                     });
                     for (int ch = nchunks - 1; ch >= 0; --ch) {
                         const int j0 = ch * N;
                         const int m = (ne - j0) < N ? (ne - j0) : N;
                         if (ch != nchunks - 1) csx.template prefetch<false>(col + j0);
-                        static_rfor<0, N>([&](auto q) {
+                        rfor_gates_below<N>(m, [&](auto q) {
                             constexpr int Q = decltype(q)::value;
-                            if (Q < m) apply_rx<N, Q>(lr, li, csx.nxt[Q].x, -csx.nxt[Q].y);
+                            apply_rx<N, Q>(lr, li, csx.nxt[Q].x, -csx.nxt[Q].y);
                         });
                         sums.put_x(gx, col + j0, m);                     // wires repeat across chunks with equal gradients
                     }
@@ -1376,9 +1387,9 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
                         const int j0 = ch * N;
                         const int m = (ne - j0) < N ? (ne - j0) : N;
                         if (ch != nchunks - 1) csx.template prefetch<false>(col + j0);
-                        static_rfor<0, N>([&](auto q) {
+                        rfor_gates_below<N>(m, [&](auto q) {
                             constexpr int Q = decltype(q)::value;
-                            if (Q < m) apply_rx<N, Q>(sr, si, csx.nxt[Q].x, -csx.nxt[Q].y);
+                            apply_rx<N, Q>(sr, si, csx.nxt[Q].x, -csx.nxt[Q].y);
                         });
                     }
                 }
@@ -1447,9 +1458,9 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
                     double gx[C::KX];
 #pragma unroll
                     for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
-                    static_for<0, N>([&](auto q) {                       // every RX of the phase commutes with X_q
+                    for_gates_below<N>(ne, [&](auto q) {                 // every RX of the phase commutes with X_q
                         constexpr int Q = decltype(q)::value;
-                        if (Q < ne) gx[Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
+                        gx[Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
                     });
                     for (int ch = nchunks - 1; ch >= 0; --ch) {
                         const int j0 = ch * N;
