@@ -1248,7 +1248,9 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
 // With 2 sigma waves a 1024-sample batch puts two waves on every SIMD (one chain-type, one sigma-type on average);
 // 1 sigma wave: 157 us, 2: 148 us, 3: 155 us, 4: 167 us per launch (pair kernel: 170 us).  A variant in which the two
 // chain waves share the sigma work by step parity (no extra waves) ran at 225 us: sigma work inside a chain wave
-// delays every later chain step.  Hand-off as in the pair kernel: monotonic LDS counters, cached reads, bounded spins.
+// delays every later chain step.  Hand-off as in the pair kernel: monotonic LDS counters, cached reads, bounded spins
+// (an overrun raises `abort`, after which every wait returns at once and the waves run out -- with wrong numbers, which
+// is the right way to fail for a hand-off bug; keeping an `ok` flag through the loops cost ~10 scalar instructions per step).
 constexpr int kSigmaWaves = 2;        // sigma waves per workgroup: step t belongs to sigma wave t % kSigmaWaves
 struct TriSync {
     int psi_prod, lam_prod, ready, abort;
@@ -1303,7 +1305,6 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
         GateStream<N> gs;
         gs.init(gates, gates_bytes, gate_ring + role * kRingBytesPerWave, lane);
         double sr[1], si[1];                            // this wave's state: psi or lambda
-        bool ok = true;
         int seen[kSigmaWaves];
 #pragma unroll
         for (int w = 0; w < kSigmaWaves; ++w) seen[w] = 0;
@@ -1318,7 +1319,7 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
             __hip_atomic_store(&sync.ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
             int seen_ready = 0;
-            ok = pair_wait_ge(&sync.ready, 1, &sync.abort, seen_ready);
+            pair_wait_ge(&sync.ready, 1, &sync.abort, seen_ready);
             double fr[1] = {psi_final[lane].x}, fi[1] = {psi_final[lane].y};
             basis_change<N, false>(fr, fi, pauli, lane);
             const double h = ham_weight<N>(klow, off, co, diag);
@@ -1347,7 +1348,7 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
             if (step >= kPairRing) {
 #pragma unroll
                 for (int w = 0; w < kSigmaWaves; ++w)
-                    ok = ok && pair_wait_ge(&sync.cursor[w], step - kPairRing + 1, &sync.abort, seen[w]);
+                    pair_wait_ge(&sync.cursor[w], step - kPairRing + 1, &sync.abort, seen[w]);
             }
 #ifdef QHEA_TRI_TIMING
             const long c1 = clock64(); tm_wait += c1 - c0;
@@ -1363,10 +1364,10 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
 #endif
         };
         gs.template prime<false>(blk - 1);
-        for (int ri = runs.nruns - 1; ri >= 0 && ok; --ri) {
+        for (int ri = runs.nruns - 1; ri >= 0; --ri) {
             const int ne = runs.enc[ri], nld = runs.ld[ri];
             const int nchunks = (ne + N - 1) / N;
-            for (int rep = 0; rep < runs.count[ri] && ok; ++rep) {
+            for (int rep = 0; rep < runs.count[ri]; ++rep) {
                 if (ne > 0) csx.template prefetch<false>(col - (ne - (nchunks - 1) * N));
                 for (int l = nld - 1; l >= 0; --l) {
                     apply_ring<N, true>(sr, si, lane, ring_rev);
@@ -1410,18 +1411,17 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
 #define TMS(x)
 #endif
         int seen_p = 0, seen_l = 0;
-        bool ok = true;
         int col = E, sub = blk, step = 0;
-        for (int ri = runs.nruns - 1; ri >= 0 && ok; --ri) {
+        for (int ri = runs.nruns - 1; ri >= 0; --ri) {
             const int ne = runs.enc[ri], nld = runs.ld[ri];
             const int nchunks = (ne + N - 1) / N;
-            for (int rep = 0; rep < runs.count[ri] && ok; ++rep) {
+            for (int rep = 0; rep < runs.count[ri]; ++rep) {
                 for (int l = nld - 1; l >= 0; --l) {
                     --sub;
                     if (step % kSigmaWaves != me) { ++step; continue; }
                     TMS(const long c0 = clock64();)
-                    ok = ok && pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
-                    ok = ok && pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
+                    pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
+                    pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
                     TMS(tm_swait += clock64() - c0;)
                     const double2* slot = psi_ring[step % kPairRing];
                     const double2 p = slot[lane];
@@ -1447,8 +1447,8 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
                 if (ne > 0 && step % kSigmaWaves != me) {
                     ++step;
                 } else if (ne > 0) {
-                    ok = ok && pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
-                    ok = ok && pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
+                    pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
+                    pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
                     const double2* slot = psi_ring[step % kPairRing];
                     double2 qv[N];
                     static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
