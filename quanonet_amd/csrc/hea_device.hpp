@@ -1022,6 +1022,7 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
 // packed kernel's reverse-sweep instructions.  Hand-off = monotonic counters in LDS with workgroup-scope
 // release/acquire; every spin is bounded (an overrun raises `abort` in LDS and both waves run out).
 constexpr int kPairRing = 16;                // published psi snapshots in flight (16 KB)
+static_assert((kPairRing & (kPairRing - 1)) == 0, "ring slots are indexed with step & (kPairRing - 1)");
 constexpr int kSpinLimit = 1 << 24;
 
 struct PairSync {
@@ -1099,7 +1100,7 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
         bool ok = true;
         auto publish = [&]() {
             if (step >= kPairRing) ok = ok && pair_wait_ge(&sync.consumed, step - kPairRing + 1, &sync.abort, seen);
-            psi_ring[step % kPairRing][lane] = make_double2(pr[0], pi[0]);
+            psi_ring[step & (kPairRing - 1)][lane] = make_double2(pr[0], pi[0]);
             ++step;
             __hip_atomic_store(&sync.produced, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
@@ -1171,7 +1172,7 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
                     --sub;
                     apply_ring<N, true>(lr, li, lane, ring_rev);
                     ok = ok && pair_wait_ge(&sync.produced, step + 1, &sync.abort, seen);
-                    const double2* slot = psi_ring[step % kPairRing];
+                    const double2* slot = psi_ring[step & (kPairRing - 1)];
                     const double2 p = slot[lane];
                     double2 qv[N];
                     static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
@@ -1200,7 +1201,7 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
                 col -= ne;
                 if (ne > 0) {
                     ok = ok && pair_wait_ge(&sync.produced, step + 1, &sync.abort, seen);
-                    const double2* slot = psi_ring[step % kPairRing];
+                    const double2* slot = psi_ring[step & (kPairRing - 1)];
                     double2 qv[N];
                     static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
                     ++step;
@@ -1353,7 +1354,7 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
 #ifdef QHEA_TRI_TIMING
             const long c1 = clock64(); tm_wait += c1 - c0;
 #endif
-            ring[step % kPairRing][lane] = make_double2(sr[0], si[0]);
+            ring[step & (kPairRing - 1)][lane] = make_double2(sr[0], si[0]);
             ++step;
             // LDS executes one wave's instructions in issue order, so the counter cannot overtake the data: a
             // compiler-only fence instead of the s_waitcnt that a workgroup-scope release store costs (1 us per launch)
@@ -1423,11 +1424,11 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
                     pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
                     pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
                     TMS(tm_swait += clock64() - c0;)
-                    const double2* slot = psi_ring[step % kPairRing];
+                    const double2* slot = psi_ring[step & (kPairRing - 1)];
                     const double2 p = slot[lane];
                     double2 qv[N];
                     static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
-                    const double2 lm = lam_ring[step % kPairRing][lane];
+                    const double2 lm = lam_ring[step & (kPairRing - 1)][lane];
                     __hip_atomic_store(&sync.cursor[me], step + kSigmaWaves, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ++step;
                     double acc3[C::KW];
@@ -1449,10 +1450,10 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
                 } else if (ne > 0) {
                     pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
                     pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
-                    const double2* slot = psi_ring[step % kPairRing];
+                    const double2* slot = psi_ring[step & (kPairRing - 1)];
                     double2 qv[N];
                     static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
-                    const double2 lm = lam_ring[step % kPairRing][lane];
+                    const double2 lm = lam_ring[step & (kPairRing - 1)][lane];
                     __hip_atomic_store(&sync.cursor[me], step + kSigmaWaves, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ++step;
                     double gx[C::KX];
