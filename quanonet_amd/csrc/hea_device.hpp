@@ -514,7 +514,9 @@ struct GateStream {
         return __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, (s + 1) * SUBBYTES, 0);
     }
     __device__ __forceinline__ void park(int s) {                   // stage -> LDS slot of sub-layer s
-        if (loader) *reinterpret_cast<u32x4*>(buf(s) + lane16) = stage;
+        // every lane stores: lanes >= 4N hold a copy of lane 0's 16 bytes (lane16 == 0 in gload and here), and writing
+        // that again is cheaper than an exec-mask branch per sub-layer
+        *reinterpret_cast<u32x4*>(buf(s) + lane16) = stage;
     }
     template <int Q>
     __device__ __forceinline__ double4 pick(int s) const {          // this lane's variant of gate (s, Q)
