@@ -782,7 +782,7 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_kernel(Runs runs, long B, int
     __shared__ double2 cs_lds[kWaves * kCsPerWave + 16];   // +16: slack for the unclamped prefetch
     __shared__ __attribute__((aligned(16))) char gate_ring[kWaves * kRingBytesPerWave];
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long wave = (long)blockIdx.x * kWaves + wib;
     const long b_raw = wave * C::SPW + (lane >> C::LB);
     const bool valid = b_raw < B;
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int
     __shared__ double red_lds[C::LDSRED ? kWaves * C::REDW : 1];
     __shared__ __attribute__((aligned(16))) char gate_ring[kWaves * kRingBytesPerWave];
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
+    const int wib = threadIdx.x >> 6;         // (scalarising it costs the n = 8 kernel 3 %: measured)
     double* red = red_lds + (C::LDSRED ? wib * C::REDW : 0);
     const long wave = (long)blockIdx.x * kWaves + wib;
     const long b_raw = wave * C::SPW + (lane >> C::LB);
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
     __shared__ PairSync sync;
 
     const int lane = threadIdx.x & 63;
-    const int role = threadIdx.x >> 6;                  // 0: psi wave, 1: lambda wave
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0: psi wave, 1: lambda wave (scalar: role branches stay scalar)
     const long wave = blockIdx.x;                       // one sample group per workgroup
     const long b_raw = wave * C::SPW + (lane >> C::LB);
     const bool valid = b_raw < B;
@@ -1284,7 +1284,8 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
     __shared__ TriSync sync;
 
     const int lane = threadIdx.x & 63;
-    const int role = threadIdx.x >> 6;                  // 0: psi, 1: lambda, 2: sigma
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // 0: psi, 1: lambda, 2..: sigma; made scalar so that
+                                                        // every role-dependent loop and wait compiles to scalar control flow
     const long wave = blockIdx.x;                       // one sample group per workgroup
     const long b_raw = wave * C::SPW + (lane >> C::LB);
     const bool valid = b_raw < B;
