@@ -586,7 +586,8 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
     const int gates_bytes = (int)((sh.blk + 2) * n_qubits * kGateBytes);
     double* partial = reinterpret_cast<double*>(ws + L.off_part);
     const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, g,
-                     state_in, nullptr, nullptr, 0.0, out, grad_x, partial, ham_pauli, use_tri()};
+                     state_in, nullptr, nullptr, 0.0, out, grad_x, partial, ham_pauli, use_tri(),
+                     L.nwaves > simd_count() ? 1 : 0};
     profile_begin(st);
     if (L.lds_bwd) {
         if (launch_lds_bwd(n_qubits, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;
@@ -678,7 +679,7 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
                      reinterpret_cast<const double2*>(ws + M.L.off_cs), ws + M.L.off_U,
                      (int)((mi.sh.blk + 2) * mi.n * kGateBytes), desc->ham_offset, desc->ham_coeff, ham_diag,
                      nullptr, nullptr, y, mi.has_bias ? params + mi.off_bias : nullptr, inv_batch_total,
-                     pr, gx, partial, desc->ham_pauli, use_tri()};
+                     pr, gx, partial, desc->ham_pauli, use_tri(), M.L.nwaves > simd_count() ? 1 : 0};
     profile_begin(st);
     if (M.L.lds_bwd) {
         if (launch_lds_bwd(mi.n, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;

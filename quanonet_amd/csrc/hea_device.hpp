@@ -815,8 +815,13 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_kernel(Runs runs, long B, int
     if (valid && klow == 0) out[b] = v[0] + (bias ? bias[0] : 0.0);
 }
 
-template <int N>
-__global__ __launch_bounds__(kWaves * 64) void bwd_kernel(Runs runs, long B, int E, int blk,
+// MINW = waves per SIMD the register allocation must leave room for.  At n = 8 / 9 the kernel wants 278 / 308 registers:
+// fine while every wave has a SIMD to itself, but once the batch puts two waves on a SIMD it pays to cap the
+// allocation at 256 (20 / 116 spilled) so that both are resident -- measured, forward + backward of 24 sub-layers,
+// uncapped / capped: n = 8 B = 1024 136 / 179 us, B = 2048 249 / 206 us, B = 4096 484 / 378 us; n = 9 B = 1024
+// 234 / 329 us, B = 2048 446 / 379 us, B = 4096 875 / 711 us.  The host picks (BwdArgs::dense).
+template <int N, int MINW = 1>
+__global__ __launch_bounds__(kWaves * 64, MINW) void bwd_kernel(Runs runs, long B, int E, int blk,
                                                           const double2* __restrict__ cs,
                                                           const char* __restrict__ gates, int gates_bytes,
                                                           double off, double co,
@@ -1496,7 +1501,8 @@ struct BwdArgs {
     Runs runs; long B; int E; int blk; const double2* cs; const char* gates; int gates_bytes; double off, co;
     const double* diag; const double* g; const double* state_in; const double* y; const double* bias; double inv_bt;
     double* out; double* grad_x; double* partial; int pauli;
-    int tri;                  // n <= 5 small-batch backward: 0 = psi/lambda pair, 1 = three waves, 2 = balanced pair
+    int tri;                  // n <= 5 small-batch backward: 0 = psi/lambda pair, 1 = psi / lambda / sigma waves
+    int dense;                // more sample groups than SIMDs: n = 8, 9 use the 256-register build of bwd_kernel
 };
 
 #ifdef QHEA_SUBSET      // development builds: -D'QHEA_SUBSET(X)=X(2) X(5)' links only those qubit counts

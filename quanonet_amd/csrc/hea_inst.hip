@@ -15,7 +15,15 @@ void QHEA_CAT(launch_fwd_, QHEA_N)(dim3 grid, hipStream_t st, const FwdArgs& a) 
                        a.co, a.diag, a.pauli, a.out, a.state_out, a.bias);
 }
 void QHEA_CAT(launch_bwd_, QHEA_N)(dim3 grid, hipStream_t st, const BwdArgs& a) {
-    hipLaunchKernelGGL(bwd_kernel<QHEA_N>, grid, dim3(kWaves * 64), 0, st, a.runs, a.B, a.E, a.blk, a.cs, a.gates, a.gates_bytes,
+#if QHEA_N == 8 || QHEA_N == 9
+    if (a.dense) {
+        hipLaunchKernelGGL((bwd_kernel<QHEA_N, 2>), grid, dim3(kWaves * 64), 0, st, a.runs, a.B, a.E, a.blk, a.cs, a.gates,
+                           a.gates_bytes, a.off, a.co, a.diag, a.pauli, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out,
+                           a.grad_x, a.partial);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL((bwd_kernel<QHEA_N, 1>), grid, dim3(kWaves * 64), 0, st, a.runs, a.B, a.E, a.blk, a.cs, a.gates, a.gates_bytes,
                        a.off, a.co, a.diag, a.pauli, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out, a.grad_x, a.partial);
 }
 
