@@ -6,7 +6,7 @@ from oracle import hea_oracle as O
 from quanonet_amd import _lib
 dev = torch.device('cuda:0')
 def t(a): return torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
-for n in (6, 7, 8, 9):
+for n in ([int(a) for a in sys.argv[1:]] or [6, 7, 8, 9]):
     cfgs = O.block_configs_quanonet(n, (8, 2, 4, 2)); E, blk = O.circuit_sizes(n, cfgs)
     rng = np.random.default_rng(0)
     w = t(rng.uniform(-3, 3, (blk, 3, n))); sh = _lib.CircuitShape(n, cfgs); off, co = O.ham_params(n)
