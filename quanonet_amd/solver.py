@@ -28,6 +28,26 @@ def shard_slice(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def regression_metrics(y_pred, y_true, dist=None, world=1):
+    """
+    MSE / MAE / Max_Error (utils/metrics.py:6-29) and relative L2 (solvers/solver_pt.py:316-321) of a test set that is
+    sharded over `world` ranks: every rank passes ITS slice of predictions and targets (torch tensors, any device);
+    four sums and one maximum are all-reduced, so every rank returns the metrics of the whole set.
+    """
+    d = (y_pred.reshape(-1) - y_true.reshape(-1)).to(torch.float64)
+    yt = y_true.reshape(-1).to(torch.float64)
+    sums = torch.stack([(d * d).sum(), d.abs().sum(), (yt * yt).sum(),
+                        torch.tensor(float(d.numel()), dtype=torch.float64, device=d.device)])
+    mx = d.abs().max() if d.numel() else torch.zeros((), dtype=torch.float64, device=d.device)
+    mx = mx.reshape(1)
+    if dist is not None and world > 1:
+        dist.all_reduce(sums)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    sse, sae, sy2, cnt = sums.tolist()
+    return {'MSE': sse / cnt, 'MAE': sae / cnt, 'Max_Error': float(mx.item()),
+            'rel_l2': float(np.sqrt(sse) / (np.sqrt(sy2) + 1e-8))}
+
+
 class FlatAdam(torch.optim.Optimizer):
     """
     torch.optim.Adam arithmetic (amsgrad=False) on the trainer's flat fp64 vector through ``qhea_adam_step``:
@@ -322,12 +342,13 @@ class PTSolver:
         if self.best_model_path and os.path.exists(self.best_model_path):
             sd = torch.load(self.best_model_path, map_location=self.device, weights_only=True)
             self.model.load_state_dict(sd)
-        y_pred = self.predict(self.test_input, batch_size=self.config.get('eval_batch_size', 4096)).cpu().numpy()
-        y_true = self.test_output
-        diff = y_pred - y_true
-        metrics = {'MSE': float(np.mean(diff ** 2)), 'MAE': float(np.mean(np.abs(diff))),
-                   'Max_Error': float(np.max(np.abs(diff))),
-                   'rel_l2': float(np.linalg.norm(diff) / (np.linalg.norm(y_true) + 1e-8))}
+        # every rank evaluates its contiguous slice of the test set (10-100x a training batch: SURVEY.md 8(f)-2);
+        # the metrics are reduced from four sums and one maximum
+        n_test = self.test_input[0].shape[0]
+        lo, hi = shard_slice(n_test, self.rank, self.world)
+        y_pred = self.predict([t[lo:hi] for t in self.test_input], batch_size=self.config.get('eval_batch_size', 4096))
+        y_true = torch.as_tensor(np.asarray(self.test_output)[lo:hi], dtype=torch.float64).to(y_pred.device)
+        metrics = regression_metrics(y_pred, y_true, self.dist, self.world)
         if self.rank == 0:
             os.makedirs(self.out_dir, exist_ok=True)
             with open(os.path.join(self.out_dir, 'metric.json'), 'w') as f:

@@ -12,7 +12,7 @@ import torch
 import torch.multiprocessing as mp
 
 from tests import helpers as H
-from quanonet_amd.solver import DataParallelTrainer, shard_slice
+from quanonet_amd.solver import DataParallelTrainer, regression_metrics, shard_slice
 
 
 def test_shard_slice_partitions_every_batch():
@@ -139,3 +139,43 @@ def test_checkpoint_roundtrip_and_name_parsing(tmp_path):
     np.testing.assert_array_equal(got['QuanONet.weight'], arr.reshape(2, 3))
     np.savez(tmp_path / 'w.npz', **st)
     assert set(ck.load_weight_file(str(tmp_path / 'w.npz'))) == set(st)
+
+
+def _metrics_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    pred, true = rng.normal(size=(1001, 1)), rng.normal(size=(1001, 1))
+    lo, hi = shard_slice(1001, rank, world)                       # uneven shards on purpose
+    m = regression_metrics(torch.tensor(pred[lo:hi]), torch.tensor(true[lo:hi]), dist, world)
+    q.put((rank, m))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_metrics_equal_the_unsharded_ones():
+    """PTSolver.evaluate shards the test set over the ranks; metrics as utils/metrics.py:6-29 and
+    the relative L2 of solvers/solver_pt.py."""
+    rng = np.random.default_rng(5)
+    pred, true = rng.normal(size=(1001, 1)), rng.normal(size=(1001, 1))
+    d = (pred - true).ravel()
+    ref = {'MSE': np.mean(d ** 2), 'MAE': np.mean(np.abs(d)), 'Max_Error': np.max(np.abs(d)),
+           'rel_l2': np.linalg.norm(d) / (np.linalg.norm(true) + 1e-8)}
+    one = regression_metrics(torch.tensor(pred), torch.tensor(true))
+    for k in ref:
+        assert abs(one[k] - ref[k]) < 1e-12, k
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_metrics_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, m in res:
+        for k in ref:
+            assert abs(m[k] - ref[k]) < 1e-12, k
