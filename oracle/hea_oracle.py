@@ -288,60 +288,123 @@ def scale_repeat(x, scale, out_features):
     return x[:, idx] * scale
 
 
+def _engine(engine):
+    """Circuit arithmetic behind the model-level functions: this module (numpy, gate by gate) by default, or
+    ``oracle.c_oracle`` (the C restatement, same call shape) for sizes where numpy would take minutes."""
+    import sys
+    return engine if engine is not None else sys.modules[__name__]
+
+
+def _freq_encode(x_in, params, prefix, out_features, scale_coeff):
+    """
+    One frequency layer (core/models_pt.py:14-68).  Trainable form when ``params`` holds
+    ``<prefix>.weights`` / ``<prefix>.bias`` (_TiledElementWise, :38-41); otherwise the fixed-scale
+    form y[:,k] = scale_coeff * x[:, k mod in] (_ScaleRepeat, :63-68), which has no parameters.
+    Returns (encoded[B,out], tiled_input[B,out], trainable).
+    """
+    x_in = np.asarray(x_in, np.float64)
+    idx = np.arange(out_features) % x_in.shape[1]
+    tiled = x_in[:, idx]
+    wkey, bkey = prefix + '.weights', prefix + '.bias'
+    if wkey in params:
+        w = np.asarray(params[wkey], np.float64).reshape(-1)
+        b = np.asarray(params[bkey], np.float64).reshape(-1)
+        assert w.shape[0] == out_features and b.shape[0] == out_features
+        return tiled * w[None, :] + b[None, :], tiled, True
+    if scale_coeff is None:
+        raise ValueError(f"no '{wkey}' in params: fixed-frequency mode needs scale_coeff")
+    return tiled * float(scale_coeff), tiled, False
+
+
 def quanonet_forward(params, branch, trunk, num_qubits, net_size, ham_bound=(-5.0, 5.0),
-                     ham_diag=None, ham_pauli='Z'):
+                     ham_diag=None, ham_pauli='Z', scale_coeff=None, engine=None):
     """
-    QuanONetPT.forward (models_pt.py:153-166), trainable-frequency form.
-    params: dict with the PT state_dict keys (branch_freq.weights, ...).
-    Returns out[B] (bias included).
+    QuanONetPT.forward (models_pt.py:153-166).  params: dict with the PT state_dict keys;
+    without the ``*_freq`` keys the fixed-frequency form (if_trainable_freq=False) with
+    ``scale_coeff`` is evaluated.  Returns out[B] (bias included).
     """
-    t_enc = tiled_elementwise(trunk, params['trunk_freq.weights'], params['trunk_freq.bias'])
-    b_enc = tiled_elementwise(branch, params['branch_freq.weights'], params['branch_freq.bias'])
+    bd, bl, td, tl = net_size
+    t_enc, _, _ = _freq_encode(trunk, params, 'trunk_freq', td * num_qubits, scale_coeff)
+    b_enc, _, _ = _freq_encode(branch, params, 'branch_freq', bd * num_qubits, scale_coeff)
     x = np.concatenate([t_enc, b_enc], axis=1)            # trunk first
     off, co = ham_params(num_qubits, *ham_bound)
     cfgs = block_configs_quanonet(num_qubits, net_size)
-    out = hea_forward(num_qubits, cfgs, x, params['quantum_layer.ansatz_weights'], off, co, ham_diag, ham_pauli)
+    out = _engine(engine).hea_forward(num_qubits, cfgs, x, params['quantum_layer.ansatz_weights'], off, co, ham_diag,
+                                      ham_pauli=ham_pauli)
     return out + float(np.asarray(params['bias']).reshape(-1)[0])
 
 
 def quanonet_loss_and_grads(params, branch, trunk, y, num_qubits, net_size,
-                            ham_bound=(-5.0, 5.0), batch_total=None, ham_pauli='Z'):
+                            ham_bound=(-5.0, 5.0), batch_total=None, ham_pauli='Z', scale_coeff=None,
+                            ham_diag=None, engine=None):
     """
     MSE(mean) loss and gradients w.r.t. every QuanONetPT parameter, restating what
     torch autograd produces for solver_pt.py:232-236.  ``batch_total`` is the global
     batch size used in the mean (defaults to len(y)); a data-parallel shard passes
     the global size so that a plain SUM over shards reproduces the full gradient.
+    Fixed-frequency models (no ``*_freq`` keys in params; pass ``scale_coeff``) have only
+    the ``bias`` and ``quantum_layer.ansatz_weights`` gradients.
     """
-    branch = np.asarray(branch, np.float64)
-    trunk = np.asarray(trunk, np.float64)
     y = np.asarray(y, np.float64).reshape(-1)
     Bt = float(batch_total if batch_total is not None else y.shape[0])
-    tw, tb = params['trunk_freq.weights'], params['trunk_freq.bias']
-    bw, bb = params['branch_freq.weights'], params['branch_freq.bias']
-    t_idx = np.arange(tw.shape[0]) % trunk.shape[1]
-    b_idx = np.arange(bw.shape[0]) % branch.shape[1]
-    t_til = trunk[:, t_idx]
-    b_til = branch[:, b_idx]
-    x = np.concatenate([t_til * tw + tb, b_til * bw + bb], axis=1)
+    bd, bl, td, tl = net_size
+    nt = td * num_qubits
+    t_enc, t_til, t_train = _freq_encode(trunk, params, 'trunk_freq', nt, scale_coeff)
+    b_enc, b_til, b_train = _freq_encode(branch, params, 'branch_freq', bd * num_qubits, scale_coeff)
+    x = np.concatenate([t_enc, b_enc], axis=1)
     off, co = ham_params(num_qubits, *ham_bound)
     cfgs = block_configs_quanonet(num_qubits, net_size)
     w = params['quantum_layer.ansatz_weights']
     bias = float(np.asarray(params['bias']).reshape(-1)[0])
-    out = hea_forward(num_qubits, cfgs, x, w, off, co, ham_pauli=ham_pauli) + bias
+    eng = _engine(engine)
+    out = eng.hea_forward(num_qubits, cfgs, x, w, off, co, ham_diag, ham_pauli=ham_pauli) + bias
     resid = out - y
     g = 2.0 * resid / Bt
-    _, gx, gw = hea_backward(num_qubits, cfgs, x, w, g, off, co, ham_pauli=ham_pauli)
-    nt = tw.shape[0]
-    grads = {
-        'trunk_freq.weights': np.sum(gx[:, :nt] * t_til, axis=0),
-        'trunk_freq.bias': np.sum(gx[:, :nt], axis=0),
-        'branch_freq.weights': np.sum(gx[:, nt:] * b_til, axis=0),
-        'branch_freq.bias': np.sum(gx[:, nt:], axis=0),
-        'quantum_layer.ansatz_weights': gw,
-        'bias': np.array([np.sum(g)]),
-    }
+    _, gx, gw = eng.hea_backward(num_qubits, cfgs, x, w, g, off, co, ham_diag, ham_pauli=ham_pauli)
+    grads = {'quantum_layer.ansatz_weights': gw, 'bias': np.array([np.sum(g)])}
+    if t_train:
+        grads['trunk_freq.weights'] = np.sum(gx[:, :nt] * t_til, axis=0)
+        grads['trunk_freq.bias'] = np.sum(gx[:, :nt], axis=0)
+    if b_train:
+        grads['branch_freq.weights'] = np.sum(gx[:, nt:] * b_til, axis=0)
+        grads['branch_freq.bias'] = np.sum(gx[:, nt:], axis=0)
     sse = float(np.sum(resid ** 2))
     return sse / Bt, grads, out
+
+
+def heaqnn_forward(params, x_in, num_qubits, net_size, ham_bound=(-5.0, 5.0), ham_diag=None, ham_pauli='Z',
+                   scale_coeff=None, engine=None):
+    """HEAQNNPT.forward (models_pt.py:205-213): out = Q(F(x)), no bias.  params: PT state_dict keys."""
+    enc, _, _ = _freq_encode(x_in, params, 'freq', net_size[0] * num_qubits, scale_coeff)
+    off, co = ham_params(num_qubits, *ham_bound)
+    cfgs = block_configs_heaqnn(num_qubits, net_size)
+    return _engine(engine).hea_forward(num_qubits, cfgs, enc, params['quantum_layer.ansatz_weights'], off, co, ham_diag,
+                                       ham_pauli=ham_pauli)
+
+
+def heaqnn_loss_and_grads(params, x_in, y, num_qubits, net_size, ham_bound=(-5.0, 5.0), batch_total=None,
+                          ham_pauli='Z', scale_coeff=None, ham_diag=None, engine=None):
+    """
+    MSE(mean) loss and gradients w.r.t. every HEAQNNPT parameter (freq.weights, freq.bias when trainable,
+    quantum_layer.ansatz_weights); same conventions as quanonet_loss_and_grads.  The reference's own HEAQNN
+    checks are compare_backends.py:219-281 and :383-449.
+    """
+    y = np.asarray(y, np.float64).reshape(-1)
+    Bt = float(batch_total if batch_total is not None else y.shape[0])
+    enc, til, train = _freq_encode(x_in, params, 'freq', net_size[0] * num_qubits, scale_coeff)
+    off, co = ham_params(num_qubits, *ham_bound)
+    cfgs = block_configs_heaqnn(num_qubits, net_size)
+    w = params['quantum_layer.ansatz_weights']
+    eng = _engine(engine)
+    out = eng.hea_forward(num_qubits, cfgs, enc, w, off, co, ham_diag, ham_pauli=ham_pauli)
+    resid = out - y
+    g = 2.0 * resid / Bt
+    _, gx, gw = eng.hea_backward(num_qubits, cfgs, enc, w, g, off, co, ham_diag, ham_pauli=ham_pauli)
+    grads = {'quantum_layer.ansatz_weights': gw}
+    if train:
+        grads['freq.weights'] = np.sum(gx * til, axis=0)
+        grads['freq.bias'] = np.sum(gx, axis=0)
+    return float(np.sum(resid ** 2)) / Bt, grads, out
 
 
 # --------------------------------------------------------------------------

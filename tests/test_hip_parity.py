@@ -308,12 +308,12 @@ def test_fused_model_path_matches_oracle_and_autograd(dev, n, net, tf, backward_
     flat = fused.loss_and_grad(_t(br, dev), _t(tr, dev), _t(y, dev), global_batch=2 * B).clone()
     pred = _lib.model_forward(fused.desc, _t(br, dev), _t(tr, dev), fused.pflat).cpu().numpy()
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    if tf:
-        rl, rg, ro = O.quanonet_loss_and_grads(sd, br, tr, y, n, net, batch_total=2 * B)
-        ref = np.concatenate([rg[k].reshape(-1) for k, _ in model.named_parameters()])
-        np.testing.assert_allclose(pred, ro, rtol=0, atol=TOL)
-        np.testing.assert_allclose(flat[:-2].cpu().numpy(), ref, rtol=0, atol=TOL)
-        assert abs(flat[-2].item() - rl * 2 * B) < 1e-9
+    # trainable-frequency and fixed-frequency (_ScaleRepeat, core/models_pt.py:44-68) forms both against the oracle
+    rl, rg, ro = O.quanonet_loss_and_grads(sd, br, tr, y, n, net, batch_total=2 * B, scale_coeff=None if tf else 0.1)
+    ref = np.concatenate([rg[k].reshape(-1) for k, _ in model.named_parameters()])
+    np.testing.assert_allclose(pred, ro, rtol=0, atol=TOL)
+    np.testing.assert_allclose(flat[:-2].cpu().numpy(), ref, rtol=0, atol=TOL)
+    assert abs(flat[-2].item() - rl * 2 * B) < 1e-9
     assert abs(flat[-1].item() - float((y ** 2).sum())) < 1e-9
     # autograd path on the same module
     auto = DataParallelTrainer(model, lr=1e-3, fused=False)
@@ -336,6 +336,12 @@ def test_fused_heaqnn_path(dev):
     auto = DataParallelTrainer(model, fused=False)
     f2 = auto.loss_and_grad(_t(x, dev), _t(y, dev).unsqueeze(-1))
     np.testing.assert_allclose(f1.cpu().numpy(), f2.cpu().numpy(), rtol=0, atol=TOL)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    rl, rg, ro = O.heaqnn_loss_and_grads(sd, x, y, 5, (3, 2))
+    ref = np.concatenate([rg[k].reshape(-1) for k, _ in model.named_parameters()])
+    np.testing.assert_allclose(f1[:-2].cpu().numpy(), ref, rtol=0, atol=TOL)
+    np.testing.assert_allclose(f2[:-2].cpu().numpy(), ref, rtol=0, atol=TOL)
+    assert abs(f1[-2].item() - rl * 33) < 1e-9
 
 
 def test_training_reduces_loss_and_steps_are_deterministic(dev):

@@ -182,3 +182,105 @@ def test_pauli_readout_against_dense_operator(pauli):
             O.hea_forward(n, cfgs, x, w, 0.0, 1.0, ham_diag=np.ones(16), ham_pauli=pauli)
         with pytest.raises(ValueError):
             C.hea_forward(n, cfgs, x, w, 0.0, 1.0, ham_diag=np.ones(16), ham_pauli=pauli)
+
+
+def _fd_check(loss_fn, p, grads, eps=1e-6, tol=1e-7):
+    for key in grads:
+        flat = p[key].reshape(-1)
+        for i in {0, flat.size // 2, flat.size - 1}:
+            old = flat[i]
+            flat[i] = old + eps
+            lp = loss_fn(p)
+            flat[i] = old - eps
+            lm = loss_fn(p)
+            flat[i] = old
+            assert abs((lp - lm) / (2 * eps) - grads[key].reshape(-1)[i]) < tol, (key, i)
+
+
+def test_heaqnn_loss_grads_finite_difference_and_c_engine():
+    """HEAQNNPT (core/models_pt.py:169-213): the reference ships no HEAQNN checkpoint or gradient vector, so the
+    model-level HEAQNN oracle is pinned by central differences of its own forward, in the trainable- and the
+    fixed-frequency form, and the C engine must give the same numbers as the numpy one."""
+    n, ns = 3, (3, 2)
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(7, 4)); y = rng.normal(size=7)
+    w = rng.uniform(-3, 3, (6, 3, n))
+    for p, scale in [({'freq.weights': rng.normal(size=9), 'freq.bias': rng.normal(size=9),
+                       'quantum_layer.ansatz_weights': w.copy()}, None),
+                     ({'quantum_layer.ansatz_weights': w.copy()}, 0.3)]:
+        loss, grads, out = O.heaqnn_loss_and_grads(p, x, y, n, ns, ham_bound=(-2.0, 4.0), scale_coeff=scale)
+        assert set(grads) == set(p)
+        np.testing.assert_allclose(out, O.heaqnn_forward(p, x, n, ns, ham_bound=(-2.0, 4.0), scale_coeff=scale), atol=1e-14)
+        assert abs(loss - np.mean((out - y) ** 2)) < 1e-14
+        _fd_check(lambda q: O.heaqnn_loss_and_grads(q, x, y, n, ns, ham_bound=(-2.0, 4.0), scale_coeff=scale)[0], p, grads)
+        lc, gc, oc = O.heaqnn_loss_and_grads(p, x, y, n, ns, ham_bound=(-2.0, 4.0), scale_coeff=scale, engine=C)
+        np.testing.assert_allclose(oc, out, rtol=0, atol=1e-13)
+        for k in grads:
+            np.testing.assert_allclose(gc[k], grads[k], rtol=0, atol=1e-12, err_msg=k)
+    # batch_total: a shard weighted with the global size sums to the full gradient
+    p = {'freq.weights': rng.normal(size=9), 'freq.bias': rng.normal(size=9), 'quantum_layer.ansatz_weights': w}
+    _, gfull, _ = O.heaqnn_loss_and_grads(p, x, y, n, ns)
+    _, ga, _ = O.heaqnn_loss_and_grads(p, x[:3], y[:3], n, ns, batch_total=7)
+    _, gb, _ = O.heaqnn_loss_and_grads(p, x[3:], y[3:], n, ns, batch_total=7)
+    for k in gfull:
+        np.testing.assert_allclose(ga[k] + gb[k], gfull[k], rtol=0, atol=1e-13)
+
+
+def test_fixed_frequency_quanonet_grads():
+    """if_trainable_freq=False (_ScaleRepeat, core/models_pt.py:44-68; paper configuration FF 40-2-40-2,
+    scripts/reproduce_benchmarks1.sh:53-68): only bias and ansatz weights are trainable."""
+    n, ns = 2, (3, 1, 2, 2)
+    rng = np.random.default_rng(6)
+    p = {'quantum_layer.ansatz_weights': rng.uniform(-3, 3, (7, 3, n)), 'bias': np.array([-0.1])}
+    br = rng.normal(size=(5, 5)); tr = rng.uniform(size=(5, 1)); y = rng.normal(size=5)
+    loss, grads, out = O.quanonet_loss_and_grads(p, br, tr, y, n, ns, scale_coeff=0.25)
+    assert set(grads) == {'bias', 'quantum_layer.ansatz_weights'}
+    # the encoding is scale * tiled input, trunk columns first
+    x = np.concatenate([O.scale_repeat(tr, 0.25, 2 * n), O.scale_repeat(br, 0.25, 3 * n)], axis=1)
+    ref = O.hea_forward(n, O.block_configs_quanonet(n, ns), x, p['quantum_layer.ansatz_weights'], *O.ham_params(n)) - 0.1
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-14)
+    _fd_check(lambda q: O.quanonet_loss_and_grads(q, br, tr, y, n, ns, scale_coeff=0.25)[0], p, grads)
+    with pytest.raises(ValueError):
+        O.quanonet_loss_and_grads(p, br, tr, y, n, ns)          # FF needs the scale
+
+
+@pytest.mark.parametrize('kind', ['quanonet_tf', 'quanonet_ff', 'heaqnn_tf', 'heaqnn_ff'])
+def test_model_level_oracle_equals_torch_autograd_through_the_product_modules(kind):
+    """Independent statement of the classical chain: the product's QuanONetPT / HEAQNNPT modules (torch ops for the
+    frequency layers, concat and bias) with the quantum layer swapped for the oracle test double, differentiated by
+    torch autograd, against the closed-form sums of oracle/hea_oracle.py."""
+    import torch
+    from quanonet_amd.models import QuanONetPT, HEAQNNPT
+    rng = np.random.default_rng(8)
+    n, B = 3, 9
+    torch.manual_seed(2)
+    tf = kind.endswith('tf')
+    if kind.startswith('quanonet'):
+        net = (2, 2, 3, 1)
+        m = QuanONetPT(n, 5, 2, net, scale_coeff=0.2, if_trainable_freq=tf)
+        ins = (rng.normal(size=(B, 5)), rng.uniform(size=(B, 2)))
+    else:
+        net = (3, 2)
+        m = HEAQNNPT(n, 7, net, scale_coeff=0.2, if_trainable_freq=tf)
+        ins = (rng.normal(size=(B, 7)),)
+    q = m.quantum_layer
+    m.quantum_layer = H.make_oracle_layer(n, q.block_configs, q.ham_offset, q.ham_coeff)(q.ansatz_weights.data)
+    if tf:
+        with torch.no_grad():
+            for nm, prm in m.named_parameters():
+                if nm.endswith('.bias'):
+                    prm.copy_(torch.tensor(rng.normal(size=tuple(prm.shape))))
+    y = rng.normal(size=B)
+    out = m(*[torch.tensor(a) for a in ins])
+    loss = torch.mean((out[:, 0] - torch.tensor(y)) ** 2)
+    loss.backward()
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    if kind.startswith('quanonet'):
+        rl, rg, ro = O.quanonet_loss_and_grads(sd, ins[0], ins[1], y, n, net, scale_coeff=None if tf else 0.2)
+    else:
+        rl, rg, ro = O.heaqnn_loss_and_grads(sd, ins[0], y, n, net, scale_coeff=None if tf else 0.2)
+    np.testing.assert_allclose(out[:, 0].detach().numpy(), ro, rtol=0, atol=1e-13)
+    assert abs(loss.item() - rl) < 1e-13
+    assert {k for k, _ in m.named_parameters()} == set(rg)
+    for k, prm in m.named_parameters():
+        np.testing.assert_allclose(prm.grad.numpy().reshape(-1), rg[k].reshape(-1), rtol=0, atol=1e-12, err_msg=k)
