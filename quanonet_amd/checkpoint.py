@@ -12,7 +12,6 @@ Checkpoint / weight-format interop.
   same grammar as the reference's ``infer.py:37-86`` / ``utils/logger.py:55-118``.
 """
 import os
-import re
 import numpy as np
 
 _DTYPES = {
@@ -174,38 +173,61 @@ def pt_to_ms_state(state, model_type='QuanONet'):
     return out
 
 
-_NET_RE = re.compile(r'Net(\d+)-(\d+)-(\d+)-(\d+)')
-_NET2_RE = re.compile(r'Net(\d+)-(\d+)(?:[^-\d]|$)')
-_Q_RE = re.compile(r'_Q(\d+)')
-_S_RE = re.compile(r'_S([\d.]+?)(?:_|$)')
-_TF_RE = re.compile(r'_(TF|FF|NTF)(?:_|$)')
-_MODEL_RE = re.compile(r'_(QuanONet|HEAQNN)_')
+def _signed_list(text):
+    """'-5-5' / '0.5--1' -> numbers: the writer joins str(v) with '-' (utils/logger.py:98-103), so an empty piece
+    between two dashes announces a negative value."""
+    vals, neg = [], False
+    for piece in text.split('-'):
+        if piece == '':
+            neg = True
+            continue
+        v = float(piece)
+        vals.append(-v if neg else v)
+        neg = False
+    return vals
+
+
+_BACKEND_TOKENS = {'TQ': 'torchquantum', 'Qiskit': 'qiskit', 'PL': 'pennylane', 'HIP': 'hip',
+                   'torchquantum': 'torchquantum', 'qiskit': 'qiskit', 'pennylane': 'pennylane', 'hip': 'hip'}
 
 
 def parse_experiment_dir(path):
-    """Hyper-parameters encoded in an experiment directory name (infer.py:60-86)."""
+    """
+    Hyper-parameters encoded in an experiment directory name.  The grammar is the one the reference's logger WRITES
+    (utils/logger.py:55-118): ``<Operator>_<Model>_Net<a-b[-c-d]>_Q<n>_<TF|FF>_S<scale>[_Pauli<P>][_Diag<..>|_Ham<lo-hi>]
+    [_<backend>]_<num_train>x<num_points>_Seed<seed>``; it is read back here in ONE pass over the '_'-separated
+    fields, each recognised by its prefix.  Accepts the directory or a checkpoint file inside it (as infer.py does
+    with the same names, infer.py:60-86).  Keys absent from the name are absent from the result.
+    """
+    path = os.path.normpath(path)
     if os.path.splitext(path)[1].lower() in ('.ckpt', '.npz', '.pt', '.pth'):
-        name = os.path.basename(os.path.dirname(os.path.abspath(path)))
-    else:
-        name = os.path.basename(os.path.normpath(path))
+        path = os.path.dirname(os.path.abspath(path))
     cfg = {}
-    m = _MODEL_RE.search(name)
-    if m:
-        cfg['model_type'] = m.group(1)
-    m = _NET_RE.search(name)
-    if m:
-        cfg['net_size'] = [int(m.group(i)) for i in range(1, 5)]
-    else:
-        m = _NET2_RE.search(name)
-        if m:
-            cfg['net_size'] = [int(m.group(1)), int(m.group(2))]
-    m = _Q_RE.search(name)
-    if m:
-        cfg['num_qubits'] = int(m.group(1))
-    m = _S_RE.search(name)
-    if m:
-        cfg['scale_coeff'] = float(m.group(1))
-    m = _TF_RE.search(name)
-    if m:
-        cfg['if_trainable_freq'] = (m.group(1) == 'TF')
+    fields = os.path.basename(path).split('_')
+    for pos, tok in enumerate(fields):
+        head3, head1 = tok[:3], tok[:1]
+        if tok in ('QuanONet', 'HEAQNN', 'DeepONet', 'FNN', 'FNO') and 'model_type' not in cfg:
+            cfg['model_type'] = tok
+            if pos > 0:
+                cfg['operator'] = '_'.join(fields[:pos])
+        elif head3 == 'Net' and tok[3:4].isdigit():
+            cfg['net_size'] = [int(v) for v in tok[3:].split('-')]
+        elif head1 == 'Q' and tok[1:].isdigit():
+            cfg['num_qubits'] = int(tok[1:])
+        elif tok in ('TF', 'FF', 'NTF'):
+            cfg['if_trainable_freq'] = tok == 'TF'
+        elif head1 == 'S' and tok[1:2].isdigit():
+            cfg['scale_coeff'] = float(tok[1:])
+        elif tok.startswith('Pauli') and tok[5:] in ('X', 'Y', 'Z'):
+            cfg['ham_pauli'] = tok[5:]
+        elif tok.startswith('Diag') and len(tok) > 4:
+            cfg['ham_diag'] = _signed_list(tok[4:])
+        elif head3 == 'Ham' and len(tok) > 3:
+            cfg['ham_bound'] = _signed_list(tok[3:])
+        elif tok.startswith('Seed') and tok[4:].isdigit():
+            cfg['seed'] = int(tok[4:])
+        elif 'x' in tok and all(part.isdigit() for part in tok.split('x')) and tok.count('x') == 1:
+            cfg['num_train'], cfg['num_points'] = (int(v) for v in tok.split('x'))
+        elif tok in _BACKEND_TOKENS and 'model_type' in cfg:
+            cfg['quantum_backend'] = _BACKEND_TOKENS[tok]
     return cfg

@@ -15,10 +15,25 @@ reference's ``solvers/solver_pt.py`` (PTSolver) plus the data-parallel step the 
 """
 import json
 import os
+import random
 
 import numpy as np
 import torch
 import torch.nn as nn
+
+
+def set_random_seed(seed):
+    """
+    What the reference's launcher does before it builds the solver (utils/common.py:154-180, main.py): seed
+    ``random``, NumPy's global generator (the per-epoch ``np.random.permutation``, solver_pt.py:220) and torch (the
+    U(-pi,pi) draw of the circuit weights, core/quantum_circuits_tq.py:50-53).  PTSolver itself never seeds, exactly
+    like the reference's; in a multi-rank run only rank 0's NumPy state matters (it draws, the others receive).
+    """
+    if seed is None:
+        return
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
 
 
 def shard_slice(n_items, rank, world):
@@ -124,6 +139,9 @@ class DataParallelTrainer:
         if fused is True and self.desc is None:
             raise RuntimeError("fused training path requested but the model does not support it")
         kw = dict(optimizer_kwargs or {})
+        if optimizer.lower() == 'lbfgs':
+            # as the reference (solvers/solver_pt.py:154-155)
+            raise NotImplementedError("LBFGS requires a closure; not supported by the current training loop.")
         opt_map = {'adam': torch.optim.Adam, 'adamw': torch.optim.AdamW, 'sgd': torch.optim.SGD,
                    'rmsprop': torch.optim.RMSprop}
         cls = opt_map.get(optimizer.lower(), torch.optim.Adam)
@@ -204,18 +222,20 @@ class PTSolver:
     train_branch_input/train_trunk_input/train_output/test_* (QuanONet) or train_input/... (HEAQNN).
     """
 
-    def __init__(self, config, data_dict, device=None, dist=None, rank=0, world_size=1, log=print):
+    def __init__(self, config, data_dict, device=None, dist=None, rank=0, world_size=1, log=print, model=None):
         self.config = config
         self.data_dict = data_dict
         self.model_type = config['model_type']
         self.dist, self.rank, self.world = dist, rank, world_size
         self.log = log if rank == 0 else (lambda *a, **k: None)
         self.device = device if device is not None else torch.device('cuda')
-        if self.device.type != 'cuda':
+        # `model` is a seam for the host-logic tests (a module whose quantum layer is the oracle test double runs
+        # this very loop on the CPU); the solver never builds anything but the HIP modules itself
+        if self.device.type != 'cuda' and model is None:
             raise RuntimeError("PTSolver runs on a HIP device only (no CPU fallback)")
         self.out_dir = os.path.join(config.get('prefix') or 'outputs', config.get('operator', 'Op'),
                                     config.get('run_id', 'run'))
-        self.model = self._create_model().to(self.device)
+        self.model = (model if model is not None else self._create_model()).to(self.device)
         self.trainer = DataParallelTrainer(self.model, lr=config['learning_rate'], world_size=world_size,
                                            dist=dist, optimizer=config.get('optimizer', 'adam'),
                                            optimizer_kwargs=config.get('optimizer_kwargs', {}))
@@ -279,19 +299,37 @@ class PTSolver:
         torch.save(sd, path)
         np.savez(path.replace('.pt', '.npz'), **{k: v.detach().cpu().numpy() for k, v in sd.items()})
 
+    def _epoch_permutation(self, n):
+        """
+        ``np.random.permutation(n)`` from NumPy's global generator, as the reference draws it (solver_pt.py:220), so a
+        launcher that seeds like the reference's (``set_random_seed``) reproduces its batch order.  With several
+        ranks ONLY rank 0 draws and the order is broadcast: every rank then slices the same global batch whatever
+        its own generator state is (separately launched ranks are not seeded alike by anything).
+        """
+        if self.world > 1:
+            idx = torch.empty(n, dtype=torch.int64, device=self.device)
+            if self.rank == 0:
+                idx.copy_(torch.as_tensor(np.random.permutation(n)))
+            self.dist.broadcast(idx, src=0)
+            return idx
+        return torch.as_tensor(np.random.permutation(n), device=self.device)
+
     def train(self):
         n = self.train_output.shape[0]
         bs = min(int(self.config.get('batch_size', 100)), n)
         epochs = int(self.config['num_epochs'])
         nb = max(1, int(np.ceil(n / bs)))
         history = {'loss_train': [], 'loss_test': []}
+        trace = bool(self.config.get('trace_steps', False))     # parity tests: per-step MSE and the epoch orders
+        if trace:
+            history['loss_steps'], history['indices'] = [], []
         os.makedirs(self.out_dir, exist_ok=True)
         self.best_model_path = os.path.join(self.out_dir, 'best_model.pt')
         for epoch in range(epochs):
             self.model.train()
-            indices = np.random.permutation(n)                 # same seed on every rank -> same order
-            idx_dev = torch.as_tensor(indices, device=self.device)
+            idx_dev = self._epoch_permutation(n)
             stats = torch.zeros(3, dtype=torch.float64, device=self.device)   # sum of batch MSE, sse, sum y^2
+            steps = torch.zeros(nb, dtype=torch.float64, device=self.device) if trace else None
             for i in range(nb):
                 idx = idx_dev[i * bs:(i + 1) * bs]
                 gb = idx.numel()
@@ -303,7 +341,12 @@ class PTSolver:
                 stats[0] += tail[0] / gb
                 stats[1] += tail[0]
                 stats[2] += tail[1]
+                if trace:
+                    steps[i] = tail[0] / gb
             s = stats.tolist()                                  # one host sync per epoch
+            if trace:
+                history['loss_steps'].extend(steps.tolist())
+                history['indices'].append(idx_dev.cpu().numpy())
             avg_loss = s[0] / nb
             avg_rel = np.sqrt(s[1]) / (np.sqrt(s[2]) + 1e-8)
             history['loss_train'].append(avg_loss)
@@ -336,12 +379,19 @@ class PTSolver:
                     outs.append(o.unsqueeze(-1))
                 else:
                     outs.append(self.model(*chunk))
+        if not outs:                                            # an empty shard (fewer test rows than ranks)
+            return torch.empty((0, 1), dtype=torch.float64, device=inputs[0].device)
         return torch.cat(outs, dim=0)
 
     def evaluate(self, history=None):
-        if self.best_model_path and os.path.exists(self.best_model_path):
+        # rank 0 alone wrote best_model.pt (train()) and alone reads it back; the other ranks receive the weights by
+        # broadcast (parameters are views into the trainer's flat vector), so no rank can read a half-written file
+        # or, on node-local storage, silently evaluate different weights
+        if self.rank == 0 and self.best_model_path and os.path.exists(self.best_model_path):
             sd = torch.load(self.best_model_path, map_location=self.device, weights_only=True)
             self.model.load_state_dict(sd)
+        if self.world > 1:
+            self.trainer.broadcast_parameters()
         # every rank evaluates its contiguous slice of the test set (10-100x a training batch: SURVEY.md 8(f)-2);
         # the metrics are reduced from four sums and one maximum
         n_test = self.test_input[0].shape[0]
@@ -352,6 +402,6 @@ class PTSolver:
         if self.rank == 0:
             os.makedirs(self.out_dir, exist_ok=True)
             with open(os.path.join(self.out_dir, 'metric.json'), 'w') as f:
-                json.dump({'metrics': metrics, 'history': history}, f)
+                json.dump({'metrics': metrics, 'history': history}, f, default=lambda o: o.tolist())
         self.log(f"Test Relative L2 Error: {metrics['rel_l2']:.6f}")
         return metrics

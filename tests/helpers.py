@@ -100,3 +100,37 @@ def quanonet_with_oracle_layer(n, b_in, t_in, net, seed=0):
     q = m.quantum_layer
     m.quantum_layer = make_oracle_layer(n, q.block_configs, q.ham_offset, q.ham_coeff)(q.ansatz_weights.data)
     return m
+
+
+def swap_in_oracle_layer(model):
+    """Replace a product module's HIP quantum layer by the oracle test double (same initial weights, same dtype)."""
+    q = model.quantum_layer
+    model.quantum_layer = make_oracle_layer(q.n_wires, q.block_configs, q.ham_offset, q.ham_coeff)(q.ansatz_weights.data)
+    return model
+
+
+def load_trajectory(name):
+    """(case tuple, arrays) of tests/golden/ptsolver_trajectory.npz written by tests/golden/make_trajectory.py."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_trajectory', os.path.join(GOLDEN, 'make_trajectory.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    z = np.load(os.path.join(GOLDEN, 'ptsolver_trajectory.npz'), allow_pickle=False)
+    arrs = {k[len(name) + 1:]: z[k] for k in z.files if k.startswith(name + '/')}
+    return mod.CASES[name], arrs, mod.param_order
+
+
+def trajectory_solver_inputs(name, prefix, **extra):
+    """PTSolver config + DataManager-shaped data dict of one trajectory case (test rows = the first 40 train rows)."""
+    (model_type, n, net, b_in, t_in, N, bs, epochs, lr, scale, trainable, seed), a, order = load_trajectory(name)
+    cfg = {'model_type': model_type, 'operator': 'Trajectory', 'num_qubits': n, 'net_size': list(net),
+           'scale_coeff': scale, 'if_trainable_freq': 'true' if trainable else 'false', 'learning_rate': lr,
+           'batch_size': bs, 'num_epochs': epochs, 'prefix': prefix, 'run_id': name, 'trace_steps': True}
+    cfg.update(extra)
+    if model_type == 'QuanONet':
+        data = {'train_branch_input': a['input0'], 'train_trunk_input': a['input1'], 'train_output': a['y'],
+                'test_branch_input': a['input0'][:40], 'test_trunk_input': a['input1'][:40], 'test_output': a['y'][:40]}
+    else:
+        data = {'train_input': a['input0'], 'train_output': a['y'], 'test_input': a['input0'][:40],
+                'test_output': a['y'][:40]}
+    return cfg, data, a, order(model_type, trainable), seed

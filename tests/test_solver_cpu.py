@@ -115,10 +115,23 @@ def test_checkpoint_roundtrip_and_name_parsing(tmp_path):
     for k in st:
         np.testing.assert_array_equal(np.asarray(back[k]).reshape(-1), st[k].astype(np.float64).reshape(-1))
     cfg = ck.parse_experiment_dir('x/Advection_QuanONet_Net40-2-20-2_Q5_TF_S0.1_1000x100_Seed0/best_model.ckpt')
-    assert cfg == {'model_type': 'QuanONet', 'net_size': [40, 2, 20, 2], 'num_qubits': 5, 'scale_coeff': 0.1,
-                   'if_trainable_freq': True}
+    assert cfg == {'operator': 'Advection', 'model_type': 'QuanONet', 'net_size': [40, 2, 20, 2], 'num_qubits': 5,
+                   'scale_coeff': 0.1, 'if_trainable_freq': True, 'num_train': 1000, 'num_points': 100, 'seed': 0}
     cfg2 = ck.parse_experiment_dir('RDiffusion_HEAQNN_Net64-2_Q8_FF_S0.01_TQ_1000x100_Seed3')
     assert cfg2['model_type'] == 'HEAQNN' and cfg2['net_size'] == [64, 2] and cfg2['if_trainable_freq'] is False
+    assert cfg2['quantum_backend'] == 'torchquantum' and cfg2['seed'] == 3 and cfg2['scale_coeff'] == 0.01
+    # every optional field the reference's logger can write (utils/logger.py:55-118), incl. negative bounds
+    cfg3 = ck.parse_experiment_dir('out/Darcy_QuanONet_Net160-2-90-2_Q5_TF_S0.001_PauliX_Ham-2-6_PL_1000x25_Seed4/')
+    assert cfg3 == {'operator': 'Darcy', 'model_type': 'QuanONet', 'net_size': [160, 2, 90, 2], 'num_qubits': 5,
+                    'if_trainable_freq': True, 'scale_coeff': 0.001, 'ham_pauli': 'X', 'ham_bound': [-2.0, 6.0],
+                    'quantum_backend': 'pennylane', 'num_train': 1000, 'num_points': 25, 'seed': 4}
+    cfg4 = ck.parse_experiment_dir('Antideriv_QuanONet_Net5-1-5-1_Q2_TF_S0.001_Diag-5--2.5-2.5-5_1000x100_Seed0')
+    assert cfg4['ham_diag'] == [-5.0, -2.5, 2.5, 5.0] and 'ham_bound' not in cfg4 and cfg4['num_qubits'] == 2
+    # the names of the four shipped checkpoints' directories (pretrained_weights/**)
+    for nm in ('Antideriv_QuanONet_Net5-1-5-1_Q2_TF_S0.001_1000x100_Seed0', 'Advection_QuanONet_Net40-2-20-2_Q5_TF_S0.1_1000x100_Seed0'):
+        c = ck.parse_experiment_dir(nm)
+        assert c['model_type'] == 'QuanONet' and len(c['net_size']) == 4 and c['if_trainable_freq'] is True
+    assert ck.parse_experiment_dir('weights') == {}
     # MindSpore .ckpt reader against a protobuf written here (same wire layout as SURVEY.md 8c)
     def varint(v):
         out = b''
@@ -179,3 +192,9 @@ def test_sharded_evaluation_metrics_equal_the_unsharded_ones():
     for _, m in res:
         for k in ref:
             assert abs(m[k] - ref[k]) < 1e-12, k
+
+
+def test_lbfgs_is_rejected_like_the_reference():
+    model = H.quanonet_with_oracle_layer(N, B_IN, T_IN, NET)
+    with pytest.raises(NotImplementedError):            # solvers/solver_pt.py:154-155
+        DataParallelTrainer(model, lr=1e-2, fused=False, optimizer='lbfgs')
