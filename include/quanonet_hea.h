@@ -13,9 +13,11 @@
  * All pointers marked DEVICE are HBM addresses valid on the current HIP device;
  * pointers marked HOST are ordinary host memory read before the call returns.
  * All device work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
- * the null stream).  No entry point allocates, frees or synchronises: scratch is
- * the caller-owned `workspace` (size from qhea_workspace_bytes), so every call
- * is hipGraph-capturable.  Nothing is retained past return.
+ * the null stream).  No entry point allocates, frees or synchronises (except
+ * qhea_check_status, whose purpose is to): scratch is the caller-owned `workspace`
+ * (size from qhea_workspace_bytes; its first 256 bytes are a header the library
+ * maintains -- keep them intact between calls), so every compute call is
+ * hipGraph-capturable.  Nothing is retained past return.
  *
  * Layouts (row-major, fp64):
  *   x      [B, E]        encoding angles, column e = block*n + wire, trunk blocks first
@@ -53,6 +55,7 @@ extern "C" {
 #define QHEA_EWORKSPACE   -3   /* workspace too small / missing                       */
 #define QHEA_ELAUNCH      -4   /* HIP launch or runtime failure                       */
 #define QHEA_ENODEVICE    -5   /* no usable HIP device                                */
+#define QHEA_EPIPELINE    -6   /* a backward kernel's wave-to-wave hand-off overran (qhea_check_status) */
 
 #define QHEA_MIN_QUBITS 2      /* n=1 has no entangler in MindQuantum and an undefined one in TQ */
 #define QHEA_MAX_QUBITS 12
@@ -65,6 +68,31 @@ const char* qhea_strerror(int code);
 
 /* Number of usable HIP devices (0 when none); never initialises a context on failure. */
 int qhea_device_count(void);
+
+/*
+ * Backward-kernel variant for n <= 5 (no reference counterpart; the reference has one autograd path).
+ * QHEA_BWD_AUTO (default) chooses by batch density: the psi / lambda / sigma wave pipeline while the sample groups
+ * leave SIMDs free, the one-wave-per-group kernel otherwise.  The others force a variant (parity tests, batch sweeps).
+ * Process-wide.  The choice fixes the layout of the per-wave partial sums, so set it BEFORE qhea_workspace_bytes()
+ * and do not change it while calls that use that workspace are being issued.
+ */
+#define QHEA_BWD_AUTO   0
+#define QHEA_BWD_PACKED 1      /* one wave per sample group: forward sweep, then psi and lambda walked back together */
+#define QHEA_BWD_PAIR   2      /* psi wave + lambda wave                                                              */
+#define QHEA_BWD_TRI    3      /* psi wave + lambda wave + two inner-product (sigma) waves                            */
+int qhea_set_backward_variant(int variant);
+
+/*
+ * Failure reporting for the pipelined backward kernels (QHEA_BWD_PAIR / QHEA_BWD_TRI).  Their waves hand states to
+ * each other through LDS with bounded spins; a wait that overruns its bound aborts the workgroup's pipeline and the
+ * kernel ORs a flag into a status word at the start of `workspace`.  The SAME call's reduce kernel then writes NaN
+ * into every gradient and into the sse scalar and (qhea_model_train_step) skips the parameter update, so the failure
+ * is visible in-band without any host synchronisation.  qhea_check_status() is the explicit check: it copies the
+ * status word back on `stream`, WAITS for the stream (the only entry point that synchronises), clears the word and
+ * returns QHEA_EPIPELINE if any call since the last check overran, QHEA_OK otherwise (also for a workspace no call has
+ * used yet).  Call it where the caller synchronises anyway, e.g. once per epoch.
+ */
+int qhea_check_status(void* workspace /*DEVICE*/, size_t workspace_bytes, void* stream);
 
 /*
  * Measurement hook (no reference counterpart): the NEXT qhea_backward / qhea_model_loss_grad /

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('QHEA_LIB') or os.path.join(_HERE, 'libquanonet_hea.so
 EXPORTS = ['qhea_version', 'qhea_strerror', 'qhea_device_count', 'qhea_workspace_bytes',
            'qhea_forward', 'qhea_backward', 'qhea_model_param_count', 'qhea_model_workspace_bytes',
            'qhea_model_forward', 'qhea_model_loss_grad', 'qhea_model_train_step', 'qhea_profile_next_circuit_kernel',
-           'qhea_adam_step']
+           'qhea_adam_step', 'qhea_set_backward_variant', 'qhea_check_status']
 
 
 class ModelDesc(ctypes.Structure):
@@ -28,7 +28,8 @@ class ModelDesc(ctypes.Structure):
 
 
 MODEL_QUANONET, MODEL_HEAQNN = 0, 1
-MIN_LIB_VERSION = 300           # 0.3.0: qhea_model_train_step (0.2.0: qhea_forward/backward take ham_pauli)
+MIN_LIB_VERSION = 400           # 0.4.0: workspace header + qhea_check_status / qhea_set_backward_variant
+BWD_VARIANTS = {'auto': 0, 'packed': 1, 'pair': 2, 'tri': 3}
 PAULI = {'Z': 0, 'X': 1, 'Y': 2}
 
 
@@ -61,7 +62,7 @@ def load():
     lib.qhea_version.restype = ctypes.c_int
     if lib.qhea_version() < MIN_LIB_VERSION:
         raise QheaError(f"{LIB_PATH} is version {lib.qhea_version()}, this binding needs >= {MIN_LIB_VERSION} "
-                        f"(the ham_pauli argument changed the qhea_forward/backward signatures): rebuild it")
+                        f"(the workspace gained a status header): rebuild it")
     vp, dp = ctypes.c_void_p, ctypes.c_void_p
     i32p = ctypes.POINTER(ctypes.c_int32)
     lib.qhea_version.restype = ctypes.c_int
@@ -79,6 +80,10 @@ def load():
                                   vp, ctypes.c_size_t, vp]
     lib.qhea_profile_next_circuit_kernel.restype = ctypes.c_int
     lib.qhea_profile_next_circuit_kernel.argtypes = [vp, vp]
+    lib.qhea_set_backward_variant.restype = ctypes.c_int
+    lib.qhea_set_backward_variant.argtypes = [ctypes.c_int]
+    lib.qhea_check_status.restype = ctypes.c_int
+    lib.qhea_check_status.argtypes = [vp, ctypes.c_size_t, vp]
     lib.qhea_adam_step.restype = ctypes.c_int
     lib.qhea_adam_step.argtypes = [ctypes.c_int64, dp, dp, dp, dp, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
                                    ctypes.c_double, ctypes.c_double, ctypes.c_double, vp]
@@ -143,12 +148,36 @@ _workspaces = {}
 
 def _workspace(device, nbytes):
     """Grow-only per-device scratch tensor (caller-owned from the C ABI's point of view)."""
-    key = (device.type, device.index)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            check_status(device)                    # the old buffer's status word must not be lost when growing
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
+
+
+def set_backward_variant(name):
+    """'auto' | 'packed' | 'pair' | 'tri': qhea_set_backward_variant (n <= 5 backward kernel; tests and sweeps)."""
+    if name not in BWD_VARIANTS:
+        raise ValueError(f"backward variant must be one of {sorted(BWD_VARIANTS)} (got {name!r})")
+    _check(load().qhea_set_backward_variant(BWD_VARIANTS[name]), 'qhea_set_backward_variant')
+
+
+def check_status(device):
+    """
+    qhea_check_status on this device's workspace: waits for the current stream and raises QheaError if a pipelined
+    backward kernel reported a hand-off overrun since the last check (the gradients of that call were NaN-poisoned
+    and its fused Adam update skipped).  No-op for a device that has not run anything yet.
+    """
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None:
+        return
+    with torch.cuda.device(device):
+        rc = load().qhea_check_status(_ptr(ws), ws.numel(), _stream(device))
+    _check(rc, 'qhea_check_status')
 
 
 def _stream(device):

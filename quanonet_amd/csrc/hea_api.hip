@@ -1,7 +1,8 @@
 // hea_api.hip -- C ABI (include/quanonet_hea.h) of the MI355X HEA simulator: argument checks,
 // workspace layout, the batch-invariant prep / reduce kernels and the per-qubit-count dispatch.
+#include <atomic>
 #include <cmath>
-#include <cstdlib>
+#include <limits>
 
 #include "hea_device.hpp"
 
@@ -10,9 +11,24 @@ namespace qhea {
 // Gate table entry g = s*n+q (64 B): U = RY(w[s,2,q]) RZ(w[s,1,q]) RY(w[s,0,q]) = [[a,b],[-conj b,conj a]]
 // stored as two lane variants (ar, ai, br, bi) and (ar, -ai, -br, bi); `gates` points at entry -n
 // (n identity entries of padding on each side).  cs[b,e] = (cos, sin)(x[b,e]/2).
+// First 256 bytes of every workspace.  The caller's buffer arrives uninitialised, so the prep kernel that opens each
+// call (stream-ordered before everything else) stamps the magic and zeroes the status the first time it sees the
+// buffer; after that the status word is sticky until qhea_check_status() reads and clears it.
+struct WorkspaceHeader {
+    unsigned long long magic;
+    int status;                    // OR of kStatus* bits
+    int pad;
+};
+constexpr unsigned long long kWsMagic = 0x51484541'57530001ull;      // "QHEAWS" + layout version
+constexpr size_t kHeaderBytes = 256;
+__device__ __forceinline__ void header_init(WorkspaceHeader* h) {
+    if (h->magic != kWsMagic) { h->status = 0; h->pad = 0; h->magic = kWsMagic; }
+}
+
 __global__ void prep_kernel(int n, int blk, const double* __restrict__ w, double4* __restrict__ gates,
-                            long BE, const double* __restrict__ x, double2* __restrict__ cs) {
+                            long BE, const double* __restrict__ x, double2* __restrict__ cs, WorkspaceHeader* hdr) {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid == 0) header_init(hdr);
     const long ng = (long)(blk + 2) * n;
     if (tid < ng) {
         const long g = tid - n;                       // real gate index, or padding
@@ -85,7 +101,7 @@ __device__ __forceinline__ void adam_update(const AdamArgs& a, long i, double gi
 __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw, long nwaves,
                                                  const double* __restrict__ partial, const double* w /* may alias adam->p */,
                                                  double* __restrict__ grad_w, double* acc /*[kRedThreads]*/,
-                                                 const AdamArgs* adam = nullptr, long adam_base = 0) {
+                                                 bool poisoned, const AdamArgs* adam = nullptr, long adam_base = 0) {
     const int cols = red_cols(kw), nslices = kRedThreads / cols;
     const int j = threadIdx.x % cols, slice = threadIdx.x / cols;
     const long ncols = (long)blk * kw;
@@ -108,11 +124,12 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
             sincos(ws[n + q], &sb, &cb);
             sincos(ws[2 * n + q], &sc, &cc);
             double* gs = grad_w + (long)s * 3 * n;
-            const double gc = Y, gb = cc * Z + sc * X, ga = cb * Y - sb * cc * X + sb * sc * Z;
+            double gc = Y, gb = cc * Z + sc * X, ga = cb * Y - sb * cc * X + sb * sc * Z;
+            if (poisoned) gc = gb = ga = std::numeric_limits<double>::quiet_NaN();   // the circuit kernel reported an overrun
             gs[2 * n + q] = gc;
             gs[n + q] = gb;
             gs[q] = ga;
-            if (adam && adam->p) {               // this thread alone reads and writes the three angles of gate (s, q)
+            if (adam && adam->p && !poisoned) {  // this thread alone reads and writes the three angles of gate (s, q)
                 const long base = adam_base + (long)s * 3 * n;
                 adam_update(*adam, base + 2 * n + q, gc);
                 adam_update(*adam, base + n + q, gb);
@@ -125,9 +142,10 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
 __global__ __launch_bounds__(kRedThreads) void reduce_kernel(int n, int blk, int kw, long nwaves,
                                                              const double* __restrict__ partial,
                                                              const double* __restrict__ w,
-                                                             double* __restrict__ grad_w) {
+                                                             double* __restrict__ grad_w,
+                                                             const WorkspaceHeader* __restrict__ hdr) {
     __shared__ double acc[kRedThreads];
-    reduce_xyz_block(blockIdx.x, n, blk, kw, nwaves, partial, w, grad_w, acc);
+    reduce_xyz_block(blockIdx.x, n, blk, kw, nwaves, partial, w, grad_w, acc, hdr->status != 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -169,31 +187,34 @@ struct Layout {
 
 // Pipelined backward kernels (n <= 5): several waves per sample group (psi chain, lambda chain, sigma waves), so they
 // pay while the packed kernel would leave SIMDs without a wave (hea_device.hpp: bwd_tri_kernel, bwd_pair_kernel)
-int simd_count() {
-    static int cached = 0;
-    if (cached == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            cached = 4 * cus;
-        else
+int simd_count() {                                // of the CURRENT device (cached per device ordinal)
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> cached[kMaxDev];
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 1024;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+            v = 4 * cus;
+            cached[dev].store(v, std::memory_order_relaxed);
+        } else {
             return 1024;                               // MI355X: 256 CUs x 4 SIMDs (used when no device is visible)
+        }
     }
-    return cached;
+    return v;
 }
+// Backward-kernel choice for n <= 5: QHEA_BWD_AUTO picks by batch density (below); the parity tests and the batch
+// sweeps force a variant through qhea_set_backward_variant().  Process-wide; it decides the partial-sum layout, so it
+// must not change between qhea_workspace_bytes() and the calls that use that size.
+std::atomic<int> g_bwd_variant{QHEA_BWD_AUTO};
 int use_tri() {                                   // which pipelined variant when use_pair() says "pipelined"
-    if (const char* e = getenv("QHEA_BACKWARD_KERNEL")) {     // test hook: "pair" forces the two-wave pipeline
-        if (e[0] == 'p' && e[1] == 'a' && e[2] == 'i') return 0;
-    }
-    return 1;                                     // psi / lambda / sigma waves (bwd_tri_kernel): 148 vs 170 us at cfg 2
+    return g_bwd_variant.load(std::memory_order_relaxed) == QHEA_BWD_PAIR ? 0 : 1;   // default: psi / lambda / sigma waves
 }
 bool use_pair(int n, int64_t B) {
     if (n > 5 || B <= 0) return false;
-    if (const char* e = getenv("QHEA_BACKWARD_KERNEL")) {     // test hook: "packed" / "pair" force a variant
-        if (e[0] == 'p' && e[1] == 'a' && e[2] == 'c') return false;
-        if (e[0] == 'p' && e[1] == 'a' && e[2] == 'i') return true;
-        if (e[0] == 't') return true;
-    }
+    const int v = g_bwd_variant.load(std::memory_order_relaxed);
+    if (v == QHEA_BWD_PACKED) return false;
+    if (v == QHEA_BWD_PAIR || v == QHEA_BWD_TRI) return true;
     // measured at n = 5 (us per backward call incl. prep/reduce; packed / pipelined): B = 1024 194 / 155, B = 1536
     // 247 / 181, B = 2048 260 / 273 -- pipelined while the sample groups fill at most 3/4 of the SIMDs
     const int spw = 64 >> n;
@@ -220,7 +241,7 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     L.nwaves_fwd = round_waves((B + spw_packed - 1) / spw_packed);
     L.nwaves = L.lds_bwd ? B : round_waves((B + spw - 1) / spw);                      // backward partial rows
     if (L.pair) L.nwaves = (B + spw - 1) / spw;                                       // one row per workgroup (= sample group)
-    size_t p = 0;
+    size_t p = kHeaderBytes;                         // WorkspaceHeader
     L.off_U = p;    p = align_up(p + (size_t)(sh.blk + 2) * n * kGateBytes);
     L.off_cs = p;   p = align_up(p + (size_t)B * sh.E * sizeof(double2));
     L.off_part = p; p = align_up(p + (size_t)L.nwaves * sh.blk * padded_3n(n) * sizeof(double));
@@ -247,7 +268,7 @@ int launch_prep(int n, const Shape& sh, int64_t B, const double* w, const double
     const long blocks = (total + threads - 1) / threads;
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, n, (int)sh.blk, w,
                        reinterpret_cast<double4*>(ws + L.off_U), (long)(B * sh.E), x,
-                       reinterpret_cast<double2*>(ws + L.off_cs));
+                       reinterpret_cast<double2*>(ws + L.off_cs), reinterpret_cast<WorkspaceHeader*>(ws));
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 
@@ -263,8 +284,9 @@ struct EncSeg {                 // x[b, col0 + e] = in[b, e % width] * w[e] + bi
 struct EncDesc { EncSeg seg[2]; };
 
 __global__ void prep_model_kernel(int n, int blk, const double* __restrict__ w, double4* __restrict__ gates,
-                                  long B, int E, EncDesc enc, double2* __restrict__ cs) {
+                                  long B, int E, EncDesc enc, double2* __restrict__ cs, WorkspaceHeader* hdr) {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid == 0) header_init(hdr);
     const long ng = (long)(blk + 2) * n;
     if (tid < ng) {
         const long g = tid - n;
@@ -311,12 +333,15 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         int n, int blk, int kw, long nwaves, const double* __restrict__ partial, const double* w,
         long B, int E, EncDesc enc, const double* __restrict__ grad_x, const double* __restrict__ pred,
         const double* __restrict__ y, double inv_bt, GradMap gm, int nb_w, int nb_x, double* __restrict__ grad,
-        AdamArgs adam) {
+        AdamArgs adam, const WorkspaceHeader* __restrict__ hdr) {
     __shared__ double acc[kRedThreads];
     __shared__ double acc2[kRedThreads];
     const int bid = blockIdx.x;
+    const bool poisoned = hdr->status != 0;        // hand-off overrun in the circuit kernel: NaN out, no parameter update
+    const double kNaN = std::numeric_limits<double>::quiet_NaN();
+    if (poisoned) adam.p = nullptr;
     if (bid < nb_w) {
-        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, &adam, gm.off_ans);
+        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, poisoned, &adam, gm.off_ans);
     } else if (bid < nb_w + nb_x) {
         const int j = threadIdx.x % kFreqCols, slice = threadIdx.x / kFreqCols;
         const int e = (bid - nb_w) * kFreqCols + j;
@@ -350,6 +375,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         if (slice == 0 && e < E && gm.off_w[si] >= 0) {
             double t0 = 0.0, t1 = 0.0;
             for (int i = 0; i < kFreqSlices; ++i) { t0 += acc[i * kFreqCols + j]; t1 += acc2[i * kFreqCols + j]; }
+            if (poisoned) t0 = t1 = kNaN;
             grad[gm.off_b[si] + ee] = t0;
             grad[gm.off_w[si] + ee] = t1;
             if (adam.p) { adam_update(adam, gm.off_b[si] + ee, t0); adam_update(adam, gm.off_w[si] + ee, t1); }
@@ -372,10 +398,10 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            grad[gm.off_sse] = acc[0];
+            grad[gm.off_sse] = poisoned ? kNaN : acc[0];
             grad[gm.off_sse + 1] = red3[0];
             if (gm.off_bias >= 0) {
-                const double gbias = 2.0 * inv_bt * acc2[0];
+                const double gbias = poisoned ? kNaN : 2.0 * inv_bt * acc2[0];
                 grad[gm.off_bias] = gbias;
                 if (adam.p) adam_update(adam, gm.off_bias, gbias);
             }
@@ -481,7 +507,8 @@ int launch_prep_model(const ModelInfo& mi, int64_t B, const double* params, cons
     const int threads = 256;
     hipLaunchKernelGGL(prep_model_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0, st,
                        mi.n, (int)mi.sh.blk, params + mi.off_ans, reinterpret_cast<double4*>(ws + L.off_U),
-                       (long)B, (int)mi.sh.E, enc, reinterpret_cast<double2*>(ws + L.off_cs));
+                       (long)B, (int)mi.sh.E, enc, reinterpret_cast<double2*>(ws + L.off_cs),
+                       reinterpret_cast<WorkspaceHeader*>(ws));
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 
@@ -491,7 +518,7 @@ using namespace qhea;
 
 extern "C" {
 
-int qhea_version(void) { return 300; }
+int qhea_version(void) { return 400; }
 
 const char* qhea_strerror(int code) {
     switch (code) {
@@ -501,6 +528,7 @@ const char* qhea_strerror(int code) {
         case QHEA_EWORKSPACE: return "workspace missing or too small";
         case QHEA_ELAUNCH: return "HIP launch/runtime failure";
         case QHEA_ENODEVICE: return "no usable HIP device";
+        case QHEA_EPIPELINE: return "a pipelined backward kernel overran a hand-off wait: results of that call are invalid";
         default: return "unknown error";
     }
 }
@@ -509,6 +537,24 @@ int qhea_profile_next_circuit_kernel(void* start_event, void* stop_event) {
     g_ev_start = static_cast<hipEvent_t>(start_event);
     g_ev_stop = static_cast<hipEvent_t>(stop_event);
     return QHEA_OK;
+}
+
+int qhea_set_backward_variant(int variant) {
+    if (variant < QHEA_BWD_AUTO || variant > QHEA_BWD_TRI) return QHEA_EINVAL;
+    g_bwd_variant.store(variant, std::memory_order_relaxed);
+    return QHEA_OK;
+}
+
+int qhea_check_status(void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace || workspace_bytes < kHeaderBytes) return QHEA_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    WorkspaceHeader h{};
+    if (hipMemcpyAsync(&h, workspace, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) return QHEA_ELAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return QHEA_ELAUNCH;
+    if (h.magic != kWsMagic || h.status == 0) return QHEA_OK;         // never used, or clean
+    if (hipMemsetAsync(&static_cast<WorkspaceHeader*>(workspace)->status, 0, sizeof(int), st) != hipSuccess)
+        return QHEA_ELAUNCH;
+    return QHEA_EPIPELINE;
 }
 
 int qhea_device_count(void) {
@@ -587,7 +633,7 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
     double* partial = reinterpret_cast<double*>(ws + L.off_part);
     const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, g,
                      state_in, nullptr, nullptr, 0.0, out, grad_x, partial, ham_pauli, use_tri(),
-                     L.nwaves > simd_count() ? 1 : 0};
+                     L.nwaves > simd_count() ? 1 : 0, &reinterpret_cast<WorkspaceHeader*>(ws)->status};
     profile_begin(st);
     if (L.lds_bwd) {
         if (launch_lds_bwd(n_qubits, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;
@@ -602,7 +648,8 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
     if (sh.blk > 0) {
         const long ncols = sh.blk * padded_3n(n_qubits);
         hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((ncols + red_cols(padded_3n(n_qubits)) - 1) / red_cols(padded_3n(n_qubits)))), dim3(kRedThreads), 0, st,
-                           n_qubits, (int)sh.blk, padded_3n(n_qubits), L.nwaves, partial, w, grad_w);
+                           n_qubits, (int)sh.blk, padded_3n(n_qubits), L.nwaves, partial, w, grad_w,
+                           reinterpret_cast<const WorkspaceHeader*>(ws));
     }
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
@@ -679,7 +726,8 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
                      reinterpret_cast<const double2*>(ws + M.L.off_cs), ws + M.L.off_U,
                      (int)((mi.sh.blk + 2) * mi.n * kGateBytes), desc->ham_offset, desc->ham_coeff, ham_diag,
                      nullptr, nullptr, y, mi.has_bias ? params + mi.off_bias : nullptr, inv_batch_total,
-                     pr, gx, partial, desc->ham_pauli, use_tri(), M.L.nwaves > simd_count() ? 1 : 0};
+                     pr, gx, partial, desc->ham_pauli, use_tri(), M.L.nwaves > simd_count() ? 1 : 0,
+                     &reinterpret_cast<WorkspaceHeader*>(ws)->status};
     profile_begin(st);
     if (M.L.lds_bwd) {
         if (launch_lds_bwd(mi.n, (long)batch, st, ba) != QHEA_OK) return QHEA_ELAUNCH;
@@ -699,7 +747,7 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
     const int nb_x = mi.trainable ? (int)((mi.sh.E + kFreqCols - 1) / kFreqCols) : 0;
     hipLaunchKernelGGL(reduce_model_kernel, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
                        (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
-                       gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam);
+                       gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws));
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 

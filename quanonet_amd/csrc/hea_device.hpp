@@ -326,9 +326,6 @@ template <int N, bool REVERSE>
 __device__ __forceinline__ void apply_ring(double (&re)[Cfg<N>::R], double (&im)[Cfg<N>::R],
                                            int lane, int ring_src_x4) {
     using C = Cfg<N>;
-#ifdef QHEA_ABLATE_RING
-    return;
-#endif
     if constexpr (C::RB == 0) {                        // whole state on lanes: one gather
         re[0] = lane_gather(re[0], ring_src_x4);
         im[0] = lane_gather(im[0], ring_src_x4);
@@ -365,10 +362,6 @@ __device__ __forceinline__ void pauli_inner(const double (&pr)[Cfg<N>::R], const
                                             int lane, double& X, double& Y, double& Z) {
     using C = Cfg<N>;
     double x = 0.0, y = 0.0, z = 0.0;
-#ifdef QHEA_ABLATE_INNER
-    X = lr[0]; Y = li[0]; Z = pr[0];
-    return;
-#endif
     if constexpr (Q < C::LB) {
 #pragma unroll
         for (int r = 0; r < C::R; ++r) {
@@ -678,21 +671,11 @@ struct GradSums {
         }
     }
     __device__ __forceinline__ void put_w(const double (&acc3)[C::KW], int sub) {
-#ifdef QHEA_ABLATE_SUMS
-        double a = 0; for (int i = 0; i < C::KW; ++i) a += acc3[i];
-        asm volatile("" :: "v"(a));
-        return;
-#endif
         flush_w();
         wave_sum_put<C::KW>(acc3, red, lane, tw);
         sub_w = sub;
     }
     __device__ __forceinline__ void put_x(const double (&gx)[C::KX], int col, int m) {
-#ifdef QHEA_ABLATE_SUMS
-        double a = 0; for (int i = 0; i < C::KX; ++i) a += gx[i];
-        asm volatile("" :: "v"(a));
-        return;
-#endif
         flush_x();
         sample_sum_put<C::KX, C::LB>(gx, red, lane, tx);
         col_x = col; m_x = m;
@@ -1030,7 +1013,20 @@ __global__ __launch_bounds__(kWaves * 64, MINW) void bwd_kernel(Runs runs, long 
 // release/acquire; every spin is bounded (an overrun raises `abort` in LDS and both waves run out).
 constexpr int kPairRing = 16;                // published psi snapshots in flight (16 KB)
 static_assert((kPairRing & (kPairRing - 1)) == 0, "ring slots are indexed with step & (kPairRing - 1)");
-constexpr int kSpinLimit = 1 << 24;
+#ifndef QHEA_SPIN_LIMIT
+#define QHEA_SPIN_LIMIT (1 << 24)      // `make spin1` builds a test library with 1: every hand-off wait that is not already
+#endif                                 // satisfied overruns, which is how the failure-reporting path is exercised on a healthy GPU
+constexpr int kSpinLimit = QHEA_SPIN_LIMIT;
+
+// Device status word in the header of the caller's workspace (hea_api.hip: WorkspaceHeader).  A pipelined backward
+// kernel whose hand-off overran ORs kStatusHandoff into it before it exits; the reduce kernel of the same call then
+// poisons every gradient and the loss scalars with NaN and skips the fused Adam update, and qhea_check_status()
+// returns QHEA_EPIPELINE -- an overrun can no longer turn into silently wrong training.
+constexpr int kStatusHandoff = 1;
+__device__ __forceinline__ void report_abort(const int* abort_flag, int* status, int lane) {
+    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) && lane == 0 && status)
+        atomicOr(status, kStatusHandoff);
+}
 
 struct PairSync {
     int produced, consumed, ready, abort;
@@ -1063,7 +1059,8 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
                                                        double inv_bt,
                                                        double* __restrict__ out,
                                                        double* __restrict__ grad_x,
-                                                       double* __restrict__ partial) {
+                                                       double* __restrict__ partial,
+                                                       int* __restrict__ status) {
     using C = Cfg<N>;
     static_assert(C::R == 1 && C::LDSRED, "wave-pair kernel: all-lane layout, n <= 5");
     __shared__ double2 cs_lds[2 * kCsPerWave + 16];
@@ -1236,6 +1233,7 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
         sums.flush_w();
         sums.flush_x();
     }
+    report_abort(&sync.abort, status, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1257,8 +1255,9 @@ __global__ __launch_bounds__(128) void bwd_pair_kernel(Runs runs, long B, int E,
 // 1 sigma wave: 157 us, 2: 148 us, 3: 155 us, 4: 167 us per launch (pair kernel: 170 us).  A variant in which the two
 // chain waves share the sigma work by step parity (no extra waves) ran at 225 us: sigma work inside a chain wave
 // delays every later chain step.  Hand-off as in the pair kernel: monotonic LDS counters, cached reads, bounded spins
-// (an overrun raises `abort`, after which every wait returns at once and the waves run out -- with wrong numbers, which
-// is the right way to fail for a hand-off bug; keeping an `ok` flag through the loops cost ~10 scalar instructions per step).
+// (an overrun raises `abort`, after which every wait returns at once and the waves run out; keeping an `ok` flag through
+// the loops cost ~10 scalar instructions per step.  The numbers of such a launch are wrong, so every wave that sees the
+// flag at its end reports it in the workspace's status word: report_abort above).
 constexpr int kSigmaWaves = 2;        // sigma waves per workgroup: step t belongs to sigma wave t % kSigmaWaves
 struct TriSync {
     int psi_prod, lam_prod, ready, abort;
@@ -1278,7 +1277,8 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
                                                       double inv_bt,
                                                       double* __restrict__ out,
                                                       double* __restrict__ grad_x,
-                                                      double* __restrict__ partial) {
+                                                      double* __restrict__ partial,
+                                                      int* __restrict__ status) {
     using C = Cfg<N>;
     static_assert(C::R == 1 && C::LDSRED, "three-wave kernel: all-lane layout, n <= 5");
     __shared__ double2 cs_lds[2 * kCsPerWave + 16];
@@ -1347,30 +1347,18 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
         double2 (*ring)[64] = role == 0 ? psi_ring : lam_ring;
         int* prod = role == 0 ? &sync.psi_prod : &sync.lam_prod;
         int col = E, step = 0;
-#ifdef QHEA_TRI_TIMING
-        long tm_wait = 0, tm_pub = 0; const long tm0 = clock64();
-#endif
         auto publish = [&]() {
-#ifdef QHEA_TRI_TIMING
-            const long c0 = clock64();
-#endif
             if (step >= kPairRing) {
 #pragma unroll
                 for (int w = 0; w < kSigmaWaves; ++w)
                     pair_wait_ge(&sync.cursor[w], step - kPairRing + 1, &sync.abort, seen[w]);
             }
-#ifdef QHEA_TRI_TIMING
-            const long c1 = clock64(); tm_wait += c1 - c0;
-#endif
             ring[step & (kPairRing - 1)][lane] = make_double2(sr[0], si[0]);
             ++step;
             // LDS executes one wave's instructions in issue order, so the counter cannot overtake the data: a
             // compiler-only fence instead of the s_waitcnt that a workgroup-scope release store costs (1 us per launch)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __hip_atomic_store(prod, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef QHEA_TRI_TIMING
-            tm_pub += clock64() - c1;
-#endif
         };
         gs.template prime<false>(blk - 1);
         for (int ri = runs.nruns - 1; ri >= 0; --ri) {
@@ -1405,20 +1393,10 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
                 }
             }
         }
-#ifdef QHEA_TRI_TIMING
-        if (blockIdx.x == 7 && lane == 0)
-            printf("chain role %d steps %d: reverse %ld wait %ld pub %ld\n", role, step, clock64() - tm0, tm_wait, tm_pub);
-#endif
     } else {
         // ------------------------------------------------------------------ sigma wave: inner products + sums
         double* __restrict__ part_w = partial + wave * (long)blk * C::KW;
         const int me = role - 2;                        // this sigma wave takes the steps with step % kSigmaWaves == me
-#ifdef QHEA_TRI_TIMING
-        long tm_swait = 0; const long tm0 = clock64();
-#define TMS(x) x
-#else
-#define TMS(x)
-#endif
         int seen_p = 0, seen_l = 0;
         int col = E, sub = blk, step = 0;
         for (int ri = runs.nruns - 1; ri >= 0; --ri) {
@@ -1428,10 +1406,8 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
                 for (int l = nld - 1; l >= 0; --l) {
                     --sub;
                     if (step % kSigmaWaves != me) { ++step; continue; }
-                    TMS(const long c0 = clock64();)
                     pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
                     pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
-                    TMS(tm_swait += clock64() - c0;)
                     const double2* slot = psi_ring[step & (kPairRing - 1)];
                     const double2 p = slot[lane];
                     double2 qv[N];
@@ -1482,12 +1458,8 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
                 }
             }
         }
-#ifdef QHEA_TRI_TIMING
-        if (blockIdx.x == 7 && lane == 0)
-            printf("sigma %d: total %ld wait(sublayer steps) %ld\n", me, clock64() - tm0, tm_swait);
-#endif
-#undef TMS
     }
+    report_abort(&sync.abort, status, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1503,6 +1475,7 @@ struct BwdArgs {
     double* out; double* grad_x; double* partial; int pauli;
     int tri;                  // n <= 5 small-batch backward: 0 = psi/lambda pair, 1 = psi / lambda / sigma waves
     int dense;                // more sample groups than SIMDs: n = 8, 9 use the 256-register build of bwd_kernel
+    int* status;              // workspace status word (pipelined kernels report hand-off overruns there)
 };
 
 #ifdef QHEA_SUBSET      // development builds: -D'QHEA_SUBSET(X)=X(2) X(5)' links only those qubit counts

@@ -32,12 +32,12 @@ void QHEA_CAT(launch_bwd_pair_, QHEA_N)(dim3 grid, hipStream_t st, const BwdArgs
     if (a.tri == 1) {
         hipLaunchKernelGGL(bwd_tri_kernel<QHEA_N>, grid, dim3(128 + 64 * kSigmaWaves), 0, st, a.runs, a.B, a.E, a.blk, a.cs, a.gates,
                            a.gates_bytes, a.off, a.co, a.diag, a.pauli, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out,
-                           a.grad_x, a.partial);
+                           a.grad_x, a.partial, a.status);
         return;
     }
     hipLaunchKernelGGL(bwd_pair_kernel<QHEA_N>, grid, dim3(128), 0, st, a.runs, a.B, a.E, a.blk, a.cs, a.gates,
                        a.gates_bytes, a.off, a.co, a.diag, a.pauli, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out, a.grad_x,
-                       a.partial);
+                       a.partial, a.status);
 #else
     (void)grid; (void)st; (void)a;      // never selected for n > 5 (hea_api.hip: make_layout)
 #endif

@@ -212,6 +212,13 @@ class DataParallelTrainer:
         v = self.flat[self.numel:].tolist()
         return v[0], v[1]
 
+    def check_status(self):
+        """Raise if a backward kernel reported a hand-off overrun since the last check (qhea_check_status; that call's
+        gradients were NaN-poisoned and its Adam update skipped).  Synchronises: call where the host waits anyway."""
+        if self.pflat.is_cuda:
+            from . import _lib
+            _lib.check_status(self.pflat.device)
+
 
 class PTSolver:
     """
@@ -344,6 +351,7 @@ class PTSolver:
                 if trace:
                     steps[i] = tail[0] / gb
             s = stats.tolist()                                  # one host sync per epoch
+            self.trainer.check_status()                         # a kernel-side pipeline failure ends the run here
             if trace:
                 history['loss_steps'].extend(steps.tolist())
                 history['indices'].append(idx_dev.cpu().numpy())

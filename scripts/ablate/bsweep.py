@@ -13,7 +13,7 @@ for B in (256, 512, 768, 1024, 1280, 1536, 2048):
     x = t(rng.uniform(-3, 3, (B, E))); g = t(rng.normal(size=B))
     res = []
     for v in ('packed', 'pair', 'tri'):
-        os.environ['QHEA_BACKWARD_KERNEL'] = v
+        _lib.set_backward_variant(v)
         for _ in range(5): _lib.hea_backward(sh, x, w, g, off, co)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
         for a, b in ev:

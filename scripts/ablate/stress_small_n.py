@@ -19,7 +19,7 @@ for trial in range(120):
     ro, rgx, rgw = C.hea_backward(n, cfgs, x, w, g, off, co)
     sh = _lib.CircuitShape(n, cfgs)
     for v in ('tri', 'pair', 'packed'):
-        os.environ['QHEA_BACKWARD_KERNEL'] = v
+        _lib.set_backward_variant(v)
         gx, gw, out = _lib.hea_backward(sh, t(x), t(w), t(g), off, co, want_out=True)
         e = max(np.abs(out.cpu().numpy() - ro).max(), np.abs(gx.cpu().numpy() - rgx).max() if E else 0.0,
                 np.abs(gw.cpu().numpy() - rgw).max() if blk else 0.0)

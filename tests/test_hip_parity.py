@@ -37,11 +37,15 @@ def _run(n, cfgs, x, w, g, dev, off, co, diag=None, use_state=True, pauli='Z'):
 
 
 @pytest.fixture(params=['packed', 'pair', 'tri'])
-def backward_variant(request, monkeypatch):
+def backward_variant(request, dev):
     """The three backward kernels for n <= 5 (one wave per sample group, the psi-wave / lambda-wave pipeline, the
-    psi / lambda / sigma three-wave pipeline); the library reads the variable at every call."""
-    monkeypatch.setenv('QHEA_BACKWARD_KERNEL', request.param)
-    return request.param
+    psi / lambda / sigma three-wave pipeline), forced through qhea_set_backward_variant; afterwards the status word
+    must be clean (no hand-off overrun) and the choice goes back to automatic."""
+    from quanonet_amd import _lib
+    _lib.set_backward_variant(request.param)
+    yield request.param
+    _lib.set_backward_variant('auto')
+    _lib.check_status(dev)
 
 
 def test_golden_vectors(dev, backward_variant):

@@ -1,0 +1,105 @@
+"""
+Failure reporting of the pipelined backward kernels (VERDICT r1 item 4 / ADVICE): a hand-off wait that overruns its
+spin bound must not turn into silently wrong training.  `make spin1` builds the Q2/Q5 kernels with a spin bound of 1
+(quanonet_amd/libquanonet_hea_spin1.so), so on a healthy GPU the lambda wave's very first wait -- for the psi wave's
+50 us forward sweep -- overruns.  A child process loads that library through QHEA_LIB and checks what the caller sees.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SPIN1 = os.path.join(ROOT, 'quanonet_amd', 'libquanonet_hea_spin1.so')
+
+CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from quanonet_amd import _lib
+from quanonet_amd.models import QuanONetPT
+from quanonet_amd.solver import DataParallelTrainer, PTSolver
+assert _lib.LIB_PATH.endswith('libquanonet_hea_spin1.so'), _lib.LIB_PATH
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+rng = np.random.default_rng(0)
+B = 64
+model = QuanONetPT(5, 8, 2, (3, 2, 2, 2), scale_coeff=0.1, if_trainable_freq=True).to(dev)
+tr = DataParallelTrainer(model, lr=1e-2, fused=True)
+br = torch.tensor(rng.normal(size=(B, 8)), device=dev); tk = torch.tensor(rng.uniform(size=(B, 2)), device=dev)
+y = torch.tensor(rng.normal(size=B), device=dev)
+for variant in ('tri', 'pair'):
+    _lib.set_backward_variant(variant)
+    before = tr.pflat.clone()
+    flat = tr.train_step(br, tk, y).clone()                     # qhea_model_train_step: Adam fused into the reduce kernel
+    torch.cuda.synchronize()
+    assert torch.isnan(flat[:tr.numel]).all(), (variant, 'gradients must be NaN-poisoned')
+    assert torch.isnan(flat[tr.numel]), (variant, 'sse must be NaN')
+    assert torch.equal(tr.pflat, before), (variant, 'the fused Adam update must be skipped')
+    try:
+        tr.check_status()
+        raise SystemExit(f'{variant}: check_status did not raise')
+    except _lib.QheaError as e:
+        assert '(-6)' in str(e), str(e)
+    tr.check_status()                                           # reading the status clears it
+    tr.optimizer.t = 0
+# the packed kernel has no hand-off: same library, healthy results, clean status
+_lib.set_backward_variant('packed')
+flat = tr.train_step(br, tk, y).clone()
+torch.cuda.synchronize()
+assert torch.isfinite(flat).all() and not torch.equal(tr.pflat, before)
+tr.check_status()
+# circuit-level call: grad_w poisoned
+_lib.set_backward_variant('tri')
+sh = _lib.CircuitShape(5, [(5, 2), (5, 1)])
+x = torch.tensor(rng.uniform(-3, 3, (9, 10)), device=dev); w = torch.tensor(rng.uniform(-3, 3, (3, 3, 5)), device=dev)
+gx, gw = _lib.hea_backward(sh, x, w, torch.ones(9, dtype=torch.float64, device=dev), 0.0, 1.0)
+torch.cuda.synchronize()
+assert torch.isnan(gw).all()
+try:
+    _lib.check_status(dev); raise SystemExit('circuit-level overrun not reported')
+except _lib.QheaError:
+    pass
+# PTSolver ends the run at its per-epoch synchronisation
+data = {'train_branch_input': rng.normal(size=(128, 8)), 'train_trunk_input': rng.uniform(size=(128, 2)),
+        'train_output': rng.normal(size=(128, 1)), 'test_branch_input': rng.normal(size=(8, 8)),
+        'test_trunk_input': rng.uniform(size=(8, 2)), 'test_output': rng.normal(size=(8, 1))}
+cfg = {'model_type': 'QuanONet', 'operator': 'S', 'num_qubits': 5, 'net_size': [3, 2, 2, 2], 'scale_coeff': 0.1,
+       'if_trainable_freq': 'true', 'learning_rate': 1e-2, 'batch_size': 64, 'num_epochs': 2, 'prefix': %(tmp)r,
+       'if_save': False}
+s = PTSolver(cfg, data, device=dev, log=lambda *a, **k: None)
+try:
+    s.train(); raise SystemExit('PTSolver trained through a pipeline failure')
+except _lib.QheaError:
+    pass
+print('STATUS_REPORTING_OK')
+'''
+
+
+@pytest.mark.gpu
+def test_handoff_overrun_is_reported(tmp_path):
+    assert os.path.exists(SPIN1), "build it with `make -C quanonet_amd/csrc spin1` (__graft_entry__.build() does)"
+    env = dict(os.environ, QHEA_LIB=SPIN1)
+    r = subprocess.run([sys.executable, '-c', CHILD % {'root': ROOT, 'tmp': str(tmp_path)}], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'STATUS_REPORTING_OK' in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_status_is_clean_after_healthy_runs():
+    import numpy as np
+    import torch
+    from quanonet_amd import _lib
+    dev = torch.device('cuda:0')
+    sh = _lib.CircuitShape(5, [(5, 2), (5, 2)])
+    rng = np.random.default_rng(1)
+    x = torch.tensor(rng.uniform(-3, 3, (200, 10)), device=dev); w = torch.tensor(rng.uniform(-3, 3, (4, 3, 5)), device=dev)
+    g = torch.ones(200, dtype=torch.float64, device=dev)
+    for v in ('tri', 'pair', 'packed', 'auto'):
+        _lib.set_backward_variant(v)
+        for _ in range(20):
+            gx, gw = _lib.hea_backward(sh, x, w, g, 0.0, 1.0)
+        assert torch.isfinite(gw).all()
+        _lib.check_status(dev)
+    with pytest.raises(ValueError):
+        _lib.set_backward_variant('fastest')
