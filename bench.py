@@ -12,7 +12,6 @@ one rank per GPU.  Rank 0 prints ONE JSON line.  `value` = train samples/s over 
 also carries forward-only circuit-evals/s, the roofline object of the dominant kernel and the CPU baseline.
 """
 import argparse
-import glob
 import json
 import os
 import sys
@@ -25,25 +24,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_QUBITS, NET, B_IN, T_IN, BATCH = 5, (40, 2, 20, 2), 100, 2, 1024
-HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP64_VECTOR_PEAK_TFLOPS = 78.6   # AMD MI355X spec, FP64 vector = half of the guide's 157.3 TF FP32 vector rate
-
-
-def circuit_counts(n, net):
-    bd, bl, td, tl = net
-    E = (bd + td) * n
-    blk = bd * bl + td * tl
-    R = E + 3 * n * blk                 # rotation gates
-    G = R + n * blk                     # + CNOTs
-    S = 16 * (1 << n)                   # bytes of one fp64 complex state
-    pairs = (1 << n) // 2               # amplitude pairs one gate touches
-    fma_fwd = n * blk * pairs * 16 + E * pairs * 8            # fused SU(2): 16 FMA per pair, RX: 8
-    fma_bwd = 2 * fma_fwd + n * blk * pairs * 12 + E * pairs * 4   # adjoint gates on psi and lambda + X,Y,Z / X inner products
-    return dict(E=E, blk=blk, R=R, G=G, S=S, flops_fwd=2 * fma_fwd, flops_train=2 * (fma_fwd + fma_bwd),
-                bytes_fwd=2 * S * G + S,                 # gate-streaming model, BASELINE.md section 2
-                bytes_bwd=S * (4 * G + 2 * R),           # reverse sweep on psi and lambda + <lam|.|psi> passes
-                bytes_train=S * (6 * G + 2 * R) + S)
-
 
 def synth(rank, n_samples):
     rng = np.random.default_rng(1000 + rank)
@@ -85,6 +65,22 @@ def cpu_baseline(seconds_target=12.0):
             "forward_evals_per_s": fdone / dtf}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` invoked plainly (no launcher): start the N ranks as CHILDREN of this process --
+    which has not touched the GPU -- through torch.distributed.run, relay rank 0's JSON line, exit with their code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in r.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            print(ln)
+    raise SystemExit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -93,11 +89,17 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='collective backend; "gloo" + --same-device rehearses N>1 on one GPU')
     ap.add_argument('--same-device', action='store_true', help='rehearsal only: every rank uses cuda:0')
+    ap.add_argument('--batch', type=int, default=BATCH, help='samples per GPU and step (the headline is 1024)')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                                     # never returns
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
     if args.same_device:
@@ -111,64 +113,76 @@ def main():
             dist.init_process_group('nccl', device_id=dev)          # RCCL over xGMI
         else:
             dist.init_process_group(args.backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from quanonet_amd.models import QuanONetPT
     from quanonet_amd import _lib
     from quanonet_amd.solver import DataParallelTrainer
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import roofline_from_profiles as RF
 
+    batch = args.batch
     torch.manual_seed(0)
     model = QuanONetPT(N_QUBITS, B_IN, T_IN, NET, scale_coeff=0.1, if_trainable_freq=True).to(dev)
     trainer = DataParallelTrainer(model, lr=1e-4, world_size=world, dist=dist)
 
     n_batches = 8                                             # device-resident synthetic set, cycled
-    branch, trunk, y = synth(rank, n_batches * BATCH)
+    branch, trunk, y = synth(rank, n_batches * batch)
     branch = torch.tensor(branch, device=dev); trunk = torch.tensor(trunk, device=dev); y = torch.tensor(y, device=dev)
 
     def step(i):
-        s = (i % n_batches) * BATCH
-        return trainer.train_step(branch[s:s + BATCH], trunk[s:s + BATCH], y[s:s + BATCH],
-                                  global_batch=BATCH * world)
+        s = (i % n_batches) * batch
+        return trainer.train_step(branch[s:s + batch], trunk[s:s + batch], y[s:s + batch],
+                                  global_batch=batch * world)
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def rank_max(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_window(fn, k, first):
+        """EXACTLY k calls bracketed by barrier + synchronize on both sides; max over ranks."""
+        fence()
+        t0 = time.perf_counter()
+        for i in range(k):
+            fn(first + i)
+        fence()
+        return rank_max(time.perf_counter() - t0)
+
+    def measure(fn, k, budget_s=0.4):
+        """Median over repeated windows of exactly k steps each: one 20-step window is 3 ms, short enough for the
+        clock ramp after the idle fence to move it by several percent (BASELINE.md section 3 asks for the median)."""
+        w0 = timed_window(fn, k, 0)
+        n_win = int(min(50, max(5, np.ceil(budget_s / max(w0, 1e-6)))))
+        wins = [w0] + [timed_window(fn, k, (j + 1) * k) for j in range(n_win - 1)]
+        return float(np.median(wins)), wins
+
     for i in range(args.warmup):
         step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    samples_per_s = BATCH * world * args.steps / elapsed
+    elapsed, windows = measure(step, args.steps)
+    samples_per_s = batch * world * args.steps / elapsed
+    trainer.check_status()
 
     # forward-only circuit evaluations/s (evaluation path: qhea_model_forward), same batch
-    def fwd_only():
-        return _lib.model_forward(trainer.desc, branch[:BATCH], trunk[:BATCH], trainer.pflat)
+    def fwd_only(_i=0):
+        return _lib.model_forward(trainer.desc, branch[:batch], trunk[:batch], trainer.pflat)
     for i in range(5):
         fwd_only()
-    fence()
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        fwd_only()
-    fence()
-    fwd_elapsed = time.perf_counter() - t1
-    evals_per_s = BATCH * world * args.steps / fwd_elapsed
+    fwd_elapsed, _ = measure(fwd_only, args.steps, budget_s=0.2)
+    evals_per_s = batch * world * args.steps / fwd_elapsed
 
     # dominant kernel: the fused circuit kernel (forward sweep + MSE residual + adjoint reverse sweep) launched by
     # qhea_model_loss_grad.  Timed ALONE with HIP events recorded by the library immediately around that launch on
     # the launch stream (qhea_profile_next_circuit_kernel); profiles/ holds the rocprofv3 summary of this command.
-    cc = circuit_counts(N_QUBITS, NET)
     roof = None
     if rank == 0:
-        yb = y[:BATCH].reshape(-1).contiguous()
+        yb = y[:batch].reshape(-1).contiguous()
         reps = max(20, min(args.steps, 200))
 
         def kernel_ms(fn):
@@ -182,40 +196,16 @@ def main():
                 _lib.profile_next_circuit_kernel(a, b)
                 fn()
             torch.cuda.synchronize()
-            return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+            return float(np.median([a.elapsed_time(b) for a, b in ev]))
 
-        lg_ms = kernel_ms(lambda: trainer.loss_and_grad(branch[:BATCH], trunk[:BATCH], yb, global_batch=BATCH * world))
+        lg_ms = kernel_ms(lambda: trainer.loss_and_grad(branch[:batch], trunk[:batch], yb, global_batch=batch * world))
         fwd_ms = kernel_ms(fwd_only)
-        achieved = cc['bytes_train'] * BATCH / (lg_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
-        if pm:
-            try:
-                t = json.load(open(pm[-1]))
-                key = ([k for k in t if 'bwd_tri_kernel<5>' in k] or [k for k in t if 'bwd_pair_kernel<5>' in k]
-                       or [k for k in t if 'bwd_kernel<5>' in k])
-                traffic = float(t[key[0]]['hbm_bytes_corrected'])
-                traffic_src = os.path.relpath(pm[-1], ROOT)
-            except Exception:
-                traffic = None
-        roof = {"bound": "hbm", "kernel": "qhea::bwd_tri_kernel<5> (fused forward + MSE residual + adjoint reverse sweep as a psi-chain / "
-                          "lambda-chain / sigma-wave pipeline; qhea::bwd_kernel<5> when the batch fills the SIMDs)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src,
-                "launch_ms": lg_ms, "algorithmic_bytes_per_launch": cc['bytes_train'] * BATCH,
-                "fwd_kernel_ms": fwd_ms, "fwd_achieved": cc['bytes_fwd'] * BATCH / (fwd_ms * 1e-3) / 1e9,
-                "fp64_vector": {"achieved": cc['flops_train'] * BATCH / (lg_ms * 1e-3) / 1e12,
-                                "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": cc['flops_train'] * BATCH / (lg_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                                "flops_per_launch": cc['flops_train'] * BATCH,
-                                "note": "executed fp64 arithmetic of the same launch (fused SU(2) 16 FMA and RX 8 FMA "
-                                        "per amplitude pair, adjoint on psi and lambda, inner products) against the "
-                                        "fp64 vector peak: the second, honest ceiling for a 32-amplitude state whose "
-                                        "every 2x2 update needs a cross-lane exchange"},
-                "note": "achieved = gate-streaming algorithmic bytes (BASELINE.md section 2: S(6G+2R)+S per sample x 1024 "
-                        "samples per launch) / HIP-event duration of the kernel alone; the state is wave-resident, so the "
-                        "measured HBM traffic (PMC, bytes per launch) is inputs+outputs only and frac exceeds 1; the real "
-                        "bound is vector-ALU issue of one wave per SIMD (DESIGN.md section 3)"}
+        pmc, pmc_src = RF.load_pmc()
+        roof = RF.build_roofline(lg_ms, fwd_ms, pmc if batch == BATCH else None,
+                                 f"HIP events around the kernel's launch on its stream, median of {reps} launches, this run",
+                                 batch=batch)
+        if roof.get('traffic') is not None:
+            roof['traffic_source'] = pmc_src
 
     if rank == 0:
         cpu = None
@@ -226,9 +216,16 @@ def main():
             "value": samples_per_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Advection QuanONet Q=5 Net40-2-20-2 b_in=100 t_in=2, batch 1024 per GPU, "
+            "config": {"workload": f"Advection QuanONet Q=5 Net40-2-20-2 b_in=100 t_in=2, batch {batch} per GPU, "
                                    "fp64, Adam lr=1e-4, trainable frequency",
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}"},
+                       "global_batch": batch * world, "parallelism": f"dp{world}"},
+            "timing": {"windows": len(windows), "steps_per_window": args.steps,
+                       "ms_per_step_median": 1e3 * elapsed / args.steps,
+                       "ms_per_step_first_window": 1e3 * windows[0] / args.steps,
+                       "ms_per_step_min": 1e3 * min(windows) / args.steps,
+                       "ms_per_step_max": 1e3 * max(windows) / args.steps,
+                       "note": "value = median over windows of EXACTLY `steps` training steps each, every window "
+                               "bracketed by barrier + device synchronize, max over ranks per window"},
             "circuit_evals_per_s": evals_per_s,
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<tag>/ (written by scripts/collect_profiles.sh) into tracked files under profiles/."""
+"""Condense gpurun_out/prof_<tag>/ (written by scripts/collect_profiles.sh) into tracked files under profiles/:
+<tag>_bench.json, <tag>_bench_k20.json, <tag>_bench_kernel_stats.csv, <tag>_pmc.json (per kernel, per launch)."""
 import csv, glob, json, os, sys, collections
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 src = f'gpurun_out/prof_{tag}'
 os.makedirs('profiles', exist_ok=True)
-bench = json.loads(open(f'{src}/bench.json').read().strip().splitlines()[-1])
-json.dump(bench, open(f'profiles/{tag}_bench.json', 'w'), indent=1)
+for nm in ('bench', 'bench_k20'):
+    if os.path.exists(f'{src}/{nm}.json'):
+        line = [l for l in open(f'{src}/{nm}.json').read().strip().splitlines() if l.startswith('{')][-1]
+        json.dump(json.loads(line), open(f'profiles/{tag}_{nm}.json', 'w'), indent=1)
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # gpurun merges runs: take the latest
 stats = newest(f'{src}/trace/*/*_kernel_stats.csv')
 rows = list(csv.DictReader(open(stats)))
@@ -13,23 +16,28 @@ with open(f'profiles/{tag}_bench_kernel_stats.csv', 'w') as f:
     w = csv.writer(f); w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage'])
     for r in rows:
         w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage']])
-def pmc(sub, counter):
-    f = newest(f'{src}/{sub}/*/*counter_collection.csv')
-    d = collections.defaultdict(list)
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f'{src}/pmc_*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if r['Counter_Name'] == counter:
-            d[r['Kernel_Name']].append(float(r['Counter_Value']))
-    return {k: sum(v) / len(v) for k, v in d.items()}
-fetch, write = pmc('pmc_fetch', 'FETCH_SIZE'), pmc('pmc_write', 'WRITE_SIZE')
+        k = r['Kernel_Name']
+        if 'qhea' not in k:
+            continue
+        # keep template arguments, drop the parameter list: "void qhea::bwd_tri_kernel<5>(...)" -> "qhea::bwd_tri_kernel<5>"
+        k = k.split('(')[0].replace('void ', '')
+        acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {}
-for k in fetch:
-    if 'qhea' in k:
-        # MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of a
-        # wide (16 B/lane) coalesced read stream -> doubled; WRITE_SIZE is exact for 16-B stores (ours are 8/16 B: uncalibrated)
-        fb, wb = fetch[k] * 1024.0, write.get(k, 0.0) * 1024.0
-        out[k.split('(')[0]] = {'FETCH_SIZE_KiB': fetch[k], 'WRITE_SIZE_KiB': write.get(k, 0.0),
-                                'hbm_bytes_corrected': 2.0 * fb + wb, 'hbm_bytes_raw': fb + wb}
-json.dump(out, open(f'profiles/{tag}_pmc_traffic.json', 'w'), indent=1)
-print(json.dumps(out, indent=1))
+for k, d in acc.items():
+    e = {c: sum(v) / len(v) for c, v in d.items()}
+    e['launches_sampled'] = {c: len(v) for c, v in d.items()}
+    if 'FETCH_SIZE' in e and 'WRITE_SIZE' in e:
+        # MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of a wide
+        # (16 B/lane) coalesced read stream -> doubled; WRITE_SIZE is exact for 16-B stores (ours are 8/16 B: uncalibrated)
+        fb, wb = e['FETCH_SIZE'] * 1024.0, e['WRITE_SIZE'] * 1024.0
+        e['hbm_bytes_corrected'] = 2.0 * fb + wb
+        e['hbm_bytes_raw'] = fb + wb
+    out[k] = e
+json.dump(out, open(f'profiles/{tag}_pmc.json', 'w'), indent=1)
+for k, e in out.items():
+    print(k, {c: (round(v) if isinstance(v, float) else v) for c, v in e.items() if c != 'launches_sampled'})
 for r in rows[:8]:
     print(r['Name'][:80].ljust(80), r['Calls'], r['AverageNs'], r['Percentage'])
