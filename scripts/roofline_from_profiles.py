@@ -136,8 +136,8 @@ def build_roofline(train_kernel_ms, fwd_kernel_ms, pmc, timing_source, batch=BAT
 
 
 def newest_tag():
-    tags = sorted({re.match(r'(r\d+)_', os.path.basename(p)).group(1)
-                   for p in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json'))})
+    tags = sorted(m.group(1) for m in (re.match(r'(r\d+[a-z]*)_pmc\.json$', os.path.basename(p))
+                                       for p in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json'))) if m)
     return tags[-1] if tags else None
 
 
@@ -148,7 +148,10 @@ def load_pmc(tag=None):
     path = os.path.join(ROOT, 'profiles', f'{tag}_pmc.json')
     if not os.path.exists(path):
         return None, None
-    return json.load(open(path)), os.path.relpath(path, ROOT)
+    try:
+        return json.load(open(path)), os.path.relpath(path, ROOT)
+    except (OSError, ValueError):
+        return None, None
 
 
 def main():

@@ -1,0 +1,12 @@
+#!/bin/bash
+# one gpurun call: GPU tests, profiles of the bench command, data-parallel rehearsals on the one GPU
+set -u
+TAG=${1:-r02a}
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_$TAG.log
+bash scripts/collect_profiles.sh $TAG || echo "collect failed"
+python3 scripts/summarize_profiles.py $TAG > gpurun_out/summary_$TAG.txt 2>&1; tail -12 gpurun_out/summary_$TAG.txt
+# 2 ranks on the one GPU (gloo moves the 19 KB through the host): the data-parallel step sequence end to end
+timeout -k 10 300 python3 bench.py --gpus 2 --same-device --backend gloo --steps 100 --no-cpu-baseline > gpurun_out/dp2_same_device_$TAG.json 2> gpurun_out/dp2_same_device_$TAG.err; echo "dp2 rc=$?"; cut -c1-250 gpurun_out/dp2_same_device_$TAG.json
+timeout -k 10 120 python3 -m torch.distributed.run --standalone --nproc-per-node 1 scripts/allreduce_cost.py > gpurun_out/allreduce_cost_$TAG.json 2> gpurun_out/allreduce_cost_$TAG.err; echo "allreduce rc=$?"; cat gpurun_out/allreduce_cost_$TAG.json
