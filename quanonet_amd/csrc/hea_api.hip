@@ -211,13 +211,13 @@ int use_tri() {                                   // which pipelined variant whe
     return g_bwd_variant.load(std::memory_order_relaxed) == QHEA_BWD_PAIR ? 0 : 1;   // default: psi / lambda / sigma waves
 }
 bool use_pair(int n, int64_t B) {
-    if (n > 5 || B <= 0) return false;
+    if (n > 5 || B <= 0 || n == QHEA_EXP_N) return false;
     const int v = g_bwd_variant.load(std::memory_order_relaxed);
     if (v == QHEA_BWD_PACKED) return false;
     if (v == QHEA_BWD_PAIR || v == QHEA_BWD_TRI) return true;
     // measured at n = 5 (us per backward call incl. prep/reduce; packed / pipelined): B = 1024 194 / 155, B = 1536
     // 247 / 181, B = 2048 260 / 273 -- pipelined while the sample groups fill at most 3/4 of the SIMDs
-    const int spw = 64 >> n;
+    const int spw = 64 >> lane_bits(n);
     return 4 * ((B + spw - 1) / spw) <= 3 * (int64_t)simd_count();
 }
 
@@ -232,7 +232,7 @@ bool use_lds(int n, bool backward) {
 
 Layout make_layout(int n, const Shape& sh, int64_t B) {
     Layout L{};
-    const int spw_packed = n < 6 ? (64 >> n) : 1;
+    const int spw_packed = 64 >> lane_bits(n);
     L.lds_fwd = use_lds(n, false);
     L.lds_bwd = use_lds(n, true);
     L.pair = !L.lds_bwd && use_pair(n, B);

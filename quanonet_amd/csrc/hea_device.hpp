@@ -45,9 +45,18 @@ struct Runs {
     int ld[kMaxRuns];
 };
 
+// Layout experiment (never shipped): -DQHEA_EXP_N=5 -DQHEA_EXP_LB=4 (or 3) builds the packed
+// kernels of that qubit count with fewer lane bits and 2^(N-LB) amplitudes per lane (more samples per wave, the
+// top qubits' gates in-lane); the pipelined kernels need the all-lane layout and are compiled out of such a build.
+#ifndef QHEA_EXP_N
+#define QHEA_EXP_N 0
+#define QHEA_EXP_LB 0
+#endif
+__host__ __device__ constexpr int lane_bits(int n) { return n == QHEA_EXP_N ? QHEA_EXP_LB : (n < 6 ? n : 6); }
+
 template <int N>
 struct Cfg {
-    static constexpr int LB = N < 6 ? N : 6;        // lane bits per sample
+    static constexpr int LB = lane_bits(N);         // lane bits per sample
     static constexpr int RB = N - LB;               // register bits
     static constexpr int R = 1 << RB;               // amplitudes per lane
     static constexpr int SPW = 64 >> LB;            // samples per wave

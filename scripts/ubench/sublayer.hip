@@ -1,0 +1,76 @@
+// Cost model check for the n = 5 chain step: one wave alone on its SIMD walks `iters` sub-layers of
+//   OLD: 5 x fused SU(2) (4 cross-lane moves + 8 fp64 multiply-adds, coefficients as 2 ds_read_b128 per gate) + ring gather
+//   NEW: 1 per-lane diagonal (4 fp64 ops, 1 ds_read_b128) + 5 x RY (4 cross-lane moves + 4 fp64 ops, 1 ds_read_b128) + ring gather
+// (the ZYZ form RY(c)RZ(b)RY(a) = RZ(alpha)RY(theta)RZ(beta) with all RZ of a layer merged into one diagonal).
+// Prints s_memtime ticks (100 MHz) and wall ns per sub-layer for 1 wave per SIMD on 128 CUs.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int MASK> __device__ __forceinline__ int xi(int v) {
+    if constexpr (MASK == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, false);
+    else if constexpr (MASK == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, false);
+    else if constexpr (MASK == 4) { int t = __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, false); return __builtin_amdgcn_mov_dpp(t, 0x1B, 0xF, 0xF, false); }
+    else if constexpr (MASK == 8) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, false);
+    else return __builtin_amdgcn_ds_swizzle(v, 0x401F);
+}
+template <int MASK> __device__ __forceinline__ double xd(double v) {
+    return __hiloint2double(xi<MASK>(__double2hiint(v)), xi<MASK>(__double2loint(v)));
+}
+__device__ __forceinline__ double gather(double v, int a) {
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(a, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(a, __double2loint(v)));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(128) void k(double* out, unsigned long long* cyc, int iters) {
+    __shared__ double4 tab[2][2 * 64 * 6];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = lane; i < 2 * 64 * 6; i += 64) tab[w][i] = make_double4(0.8 + 1e-3 * i, 0.6 - 1e-3 * i, 0.36, 0.48);
+    double re = 1.0 / 8 + lane * 1e-3, im = 0.01 * lane;
+    const int ring = ((lane & 32) | ((lane * 5 + 3) & 31)) << 2;
+    const double4* t = tab[w];
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        const double4* row = t + (it & 1) * 64 * 6;
+        if constexpr (MODE == 0) {
+#define OLDGATE(M, G) { const double4 u = row[(G) * 2 * 2 + ((lane >> (G)) & 1) * 2]; const double4 v = row[(G) * 2 * 2 + ((lane >> (G)) & 1) * 2 + 1]; \
+            const double qr = xd<M>(re), qi = xd<M>(im); \
+            const double nr = u.x * re - u.y * im + v.x * qr - v.y * qi; const double ni = u.x * im + u.y * re + v.x * qi + v.y * qr; re = nr; im = ni; }
+            OLDGATE(1, 0) OLDGATE(2, 1) OLDGATE(4, 2) OLDGATE(8, 3) OLDGATE(16, 4)
+        } else {
+            { const double4 d = row[5 * 4 + (lane & 31)]; const double nr = d.x * re - d.y * im, ni = d.x * im + d.y * re; re = nr; im = ni; }
+#define NEWGATE(M, G) { const double4 u = row[(G) * 2 + ((lane >> (G)) & 1)]; const double qr = xd<M>(re), qi = xd<M>(im); \
+            re = u.x * re - u.y * qr; im = u.x * im - u.y * qi; }
+            NEWGATE(1, 0) NEWGATE(2, 1) NEWGATE(4, 2) NEWGATE(8, 3) NEWGATE(16, 4)
+        }
+        re = gather(re, ring); im = gather(im, ring);
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = re + im;
+    if (lane == 0) cyc[blockIdx.x * 2 + w] = t1 - t0;
+}
+
+template <int MODE> int run(const char* name) {
+    double* out; unsigned long long* cyc;
+    const int blocks = 256, iters = 4000;
+    CHECK(hipMalloc(&out, sizeof(double) * blocks * 128));
+    CHECK(hipMalloc(&cyc, sizeof(unsigned long long) * blocks * 2));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(128), 0, 0, out, cyc, iters);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(128), 0, 0, out, cyc, iters);
+    hipEventRecord(e1);
+    CHECK(hipDeviceSynchronize());
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(blocks * 2);
+    CHECK(hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * blocks * 2, hipMemcpyDeviceToHost));
+    double avg = 0; for (auto v : h) avg += v; avg /= h.size();
+    printf("%-44s %.2f memtime ticks (= %.0f ns) per sub-layer; wall %.1f ns per sub-layer\n", name, avg / iters, 10.0 * avg / iters, ms * 1e6 / iters);
+    return 0;
+}
+int main() {
+    run<0>("OLD  5 x fused SU(2) + ring");
+    run<1>("NEW  diagonal + 5 x RY + ring");
+    return 0;
+}
