@@ -80,6 +80,9 @@ int qhea_device_count(void);
 #define QHEA_BWD_PACKED 1      /* one wave per sample group: forward sweep, then psi and lambda walked back together */
 #define QHEA_BWD_PAIR   2      /* psi wave + lambda wave                                                              */
 #define QHEA_BWD_TRI    3      /* psi wave + lambda wave + two inner-product (sigma) waves                            */
+#define QHEA_BWD_ZTRI   4      /* the same pipeline on the ZYZ form of the gates with in-kernel (cos, sin) tables     */
+                               /* (what AUTO runs for eligible shapes; the values 1-3 also select the first-          */
+                               /* generation forward kernel, AUTO and ZTRI the ZYZ-form one)                          */
 int qhea_set_backward_variant(int variant);
 
 /*

@@ -29,7 +29,7 @@ class ModelDesc(ctypes.Structure):
 
 MODEL_QUANONET, MODEL_HEAQNN = 0, 1
 MIN_LIB_VERSION = 400           # 0.4.0: workspace header + qhea_check_status / qhea_set_backward_variant
-BWD_VARIANTS = {'auto': 0, 'packed': 1, 'pair': 2, 'tri': 3}
+BWD_VARIANTS = {'auto': 0, 'packed': 1, 'pair': 2, 'tri': 3, 'ztri': 4}
 PAULI = {'Z': 0, 'X': 1, 'Y': 2}
 
 
@@ -159,7 +159,7 @@ def _workspace(device, nbytes):
 
 
 def set_backward_variant(name):
-    """'auto' | 'packed' | 'pair' | 'tri': qhea_set_backward_variant (n <= 5 backward kernel; tests and sweeps)."""
+    """'auto' | 'packed' | 'pair' | 'tri' | 'ztri': qhea_set_backward_variant (n <= 5 kernels; tests and sweeps)."""
     if name not in BWD_VARIANTS:
         raise ValueError(f"backward variant must be one of {sorted(BWD_VARIANTS)} (got {name!r})")
     _check(load().qhea_set_backward_variant(BWD_VARIANTS[name]), 'qhea_set_backward_variant')

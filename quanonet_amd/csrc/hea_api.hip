@@ -5,6 +5,7 @@
 #include <limits>
 
 #include "hea_device.hpp"
+#include "hea_zyz.hpp"
 
 namespace qhea {
 
@@ -59,6 +60,111 @@ __global__ void prep_kernel(int n, int blk, const double* __restrict__ w, double
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// ZYZ form of the fused ansatz gate (hea_zyz.hpp):  RY(c) RZ(b) RY(a) = RZ(alpha) RY(theta) RZ(beta) exactly (both sides
+// are the same SU(2) matrix [[A, B], [-conj B, conj A]], A = cos(theta/2) e^{-i(alpha+beta)/2}, B = -sin(theta/2) e^{-i(alpha-beta)/2}).
+// Everything is done on unit phasors -- no atan2, no angle wrap: p = A/|A|, m = -B/|B|, e^{-i alpha} = p m,
+// u = e^{-i alpha/2} = sqrt(p m) (either branch), v = e^{-i beta/2} = p conj(u)  (then u v = p and u conj(v) = m).
+// A vanishing |A| or |B| leaves one phasor free: any choice reproduces the matrix, because the phasor only ever
+// multiplies the vanishing modulus.
+// ---------------------------------------------------------------------------------------
+struct GateZ {
+    double c, s;        // cos(theta/2), sin(theta/2) >= 0
+    double2 u, v;       // e^{-i alpha/2}, e^{-i beta/2}
+};
+__device__ __forceinline__ double2 cmul(const double2& a, const double2& b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cconj(const double2& a) { return make_double2(a.x, -a.y); }
+__device__ inline GateZ gate_zyz(const double* __restrict__ ws /* w + s*3*n */, int n, int q) {
+    double sa, ca, sb, cb, sc, cc;
+    sincos(0.5 * ws[q], &sa, &ca);
+    sincos(0.5 * ws[n + q], &sb, &cb);
+    sincos(0.5 * ws[2 * n + q], &sc, &cc);
+    const double m00r = cb * ca, m00i = -sb * ca, m01r = -cb * sa, m01i = sb * sa;
+    const double m10r = cb * sa, m10i = sb * sa, m11r = cb * ca, m11i = sb * ca;
+    const double Ar = cc * m00r - sc * m10r, Ai = cc * m00i - sc * m10i;
+    const double Br = cc * m01r - sc * m11r, Bi = cc * m01i - sc * m11i;
+    const double nA = sqrt(Ar * Ar + Ai * Ai), nB = sqrt(Br * Br + Bi * Bi);
+    const double r = sqrt(nA * nA + nB * nB);
+    GateZ g;
+    g.c = nA / r; g.s = nB / r;
+    const double2 p = nA > 0.0 ? make_double2(Ar / nA, Ai / nA) : make_double2(1.0, 0.0);
+    const double2 m = nB > 0.0 ? make_double2(-Br / nB, -Bi / nB) : make_double2(1.0, 0.0);
+    const double2 z = cmul(p, m);
+    double2 u;
+    if (z.x >= 0.0) { u.x = sqrt(0.5 * (1.0 + z.x)); u.y = z.y / (2.0 * u.x); }
+    else            { u.y = copysign(sqrt(0.5 * (1.0 - z.x)), z.y); u.x = z.y / (2.0 * u.y); }
+    g.u = u;
+    g.v = cmul(p, cconj(u));
+    return g;
+}
+
+// source index of the CNOT ring as a permutation of basis indices (n <= 5): after the ring, amplitude k is the old
+// amplitude ring_src_index(n, k)  (== ring_source<N>(lane, false) >> 2 of hea_device.hpp)
+__device__ __forceinline__ int ring_src_index(int n, int k) {
+    for (int i = n - 1; i >= 0; --i) k ^= ((k >> ((i + 1) % n)) & 1) << i;
+    return k;
+}
+struct LayerInfo { int kind; int s; int m; };      // kind 0: RX chunk of m gates, 1: ansatz sub-layer s, 2: none
+__device__ inline LayerInfo decode_layer(const Runs& r, int n, int l) {
+    LayerInfo none{2, 0, 0};
+    if (l < 0) return none;
+    int s_base = 0;
+    for (int i = 0; i < r.nruns; ++i) {
+        const int nch = (r.enc[i] + n - 1) / n, per = nch + r.ld[i];
+        const long tot = (long)per * r.count[i];
+        if (l < tot) {
+            const int rep = l / per, idx = l % per;
+            if (idx < nch) {
+                const int left = r.enc[i] - idx * n;
+                return LayerInfo{0, 0, left < n ? left : n};
+            }
+            return LayerInfo{1, s_base + rep * r.ld[i] + (idx - nch), 0};
+        }
+        l -= (int)tot;
+        s_base += r.ld[i] * r.count[i];
+    }
+    return none;
+}
+
+// One 64-thread block per layer record l = 0 .. L (hea_zyz.hpp): thread k < 2^n writes the diagonal entry
+//   e^{i Phi_l(k)} = prod_q [pre-diagonal RZ(beta_q) of layer l, if it is an ansatz sub-layer]
+//                  x prod_q [post-diagonal RZ(alpha_q) of layer l-1, if THAT is an ansatz sub-layer, seen through its ring];
+// threads 32 .. 32+2n write the RY coefficients of an ansatz layer.  Native RX chunks have no diagonals of their own.
+__global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, const double* __restrict__ w,
+                                                      char* __restrict__ rec, WorkspaceHeader* hdr) {
+    const int l = blockIdx.x, j = threadIdx.x;
+    if (l == 0 && j == 0) header_init(hdr);
+    const LayerInfo cur = decode_layer(runs, n, l < L ? l : -1), prev = decode_layer(runs, n, l - 1);
+    char* out = rec + (long)l * kRecBytes;
+    if (j < (1 << n)) {
+        double2 ph = make_double2(1.0, 0.0);
+        if (cur.kind == 1) {
+            for (int q = 0; q < n; ++q) {
+                const GateZ g = gate_zyz(w + (long)cur.s * 3 * n, n, q);
+                ph = cmul(ph, ((j >> q) & 1) ? cconj(g.v) : g.v);
+            }
+        }
+        if (prev.kind == 1) {
+            const int h = ring_src_index(n, j);
+            for (int q = 0; q < n; ++q) {
+                const GateZ g = gate_zyz(w + (long)prev.s * 3 * n, n, q);
+                ph = cmul(ph, ((h >> q) & 1) ? cconj(g.u) : g.u);
+            }
+        }
+        reinterpret_cast<double2*>(out)[j] = ph;
+    } else if (j >= 32 && j < 32 + 2 * n) {
+        const int q = (j - 32) >> 1, var = (j - 32) & 1;
+        double2 e = make_double2(1.0, 0.0);
+        if (cur.kind == 1) {
+            const GateZ g = gate_zyz(w + (long)cur.s * 3 * n, n, q);
+            e = make_double2(g.c, var ? g.s : -g.s);
+        }
+        *reinterpret_cast<double2*>(out + kRecRy + q * 32 + var * 16) = e;
+    }
+}
+
 // Deterministic column sums of a row-major [rows, ncols] matrix: a block owns `cols` consecutive columns
 // (cols = max(16, kw), so a sub-layer's X,Y,Z triples never straddle blocks) and splits the rows over
 // kRedThreads/cols slices (8 independent loads in flight per thread); partial sums are combined in slice
@@ -101,7 +207,7 @@ __device__ __forceinline__ void adam_update(const AdamArgs& a, long i, double gi
 __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw, long nwaves,
                                                  const double* __restrict__ partial, const double* w /* may alias adam->p */,
                                                  double* __restrict__ grad_w, double* acc /*[kRedThreads]*/,
-                                                 bool poisoned, const AdamArgs* adam = nullptr, long adam_base = 0) {
+                                                 bool poisoned, bool zyz, const AdamArgs* adam = nullptr, long adam_base = 0) {
     const int cols = red_cols(kw), nslices = kRedThreads / cols;
     const int j = threadIdx.x % cols, slice = threadIdx.x / cols;
     const long ncols = (long)blk * kw;
@@ -118,8 +224,17 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
         const int s = (int)(v / kw), r = (int)(v % kw);
         if (r < 3 * n && r % 3 == 0) {
             const int q = r / 3;
-            const double X = acc[j], Y = acc[j + 1], Z = acc[j + 2];
+            double X = acc[j], Y = acc[j + 1];
+            const double Z = acc[j + 2];
             const double* ws = w + (long)s * 3 * n;
+            if (zyz) {      // sums taken after the RY layer, before D_post = RZ(alpha): rotate (X, Y) by alpha (hea_zyz.hpp)
+                const GateZ gz = gate_zyz(ws, n, q);
+                const double2 z = cmul(gz.u, gz.u);                  // e^{-i alpha}
+                const double ca = z.x, sa = -z.y;
+                const double Xr = ca * X - sa * Y;
+                Y = ca * Y + sa * X;
+                X = Xr;
+            }
             double sb, cb, sc, cc;
             sincos(ws[n + q], &sb, &cb);
             sincos(ws[2 * n + q], &sc, &cc);
@@ -143,9 +258,9 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(int n, int blk, int
                                                              const double* __restrict__ partial,
                                                              const double* __restrict__ w,
                                                              double* __restrict__ grad_w,
-                                                             const WorkspaceHeader* __restrict__ hdr) {
+                                                             const WorkspaceHeader* __restrict__ hdr, int zyz) {
     __shared__ double acc[kRedThreads];
-    reduce_xyz_block(blockIdx.x, n, blk, kw, nwaves, partial, w, grad_w, acc, hdr->status != 0);
+    reduce_xyz_block(blockIdx.x, n, blk, kw, nwaves, partial, w, grad_w, acc, hdr->status != 0, zyz != 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -180,9 +295,11 @@ int make_shape(int n, int nb, const int32_t* enc, const int32_t* ld, Shape& sh) 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t off_U, off_cs, off_part, total;
+    size_t off_U, off_cs, off_part, off_rec, total;
     long nwaves, nwaves_fwd;
     bool lds_fwd, lds_bwd, pair;
+    bool zfwd, ztri;        // ZYZ-form kernels of hea_zyz.hpp (n <= 5): forward / pipelined backward
+    int zL;                 // their layer count (records 0 .. zL)
 };
 
 // Pipelined backward kernels (n <= 5): several waves per sample group (psi chain, lambda chain, sigma waves), so they
@@ -214,7 +331,7 @@ bool use_pair(int n, int64_t B) {
     if (n > 5 || B <= 0 || n == QHEA_EXP_N) return false;
     const int v = g_bwd_variant.load(std::memory_order_relaxed);
     if (v == QHEA_BWD_PACKED) return false;
-    if (v == QHEA_BWD_PAIR || v == QHEA_BWD_TRI) return true;
+    if (v == QHEA_BWD_PAIR || v == QHEA_BWD_TRI || v == QHEA_BWD_ZTRI) return true;
     // measured at n = 5 (us per backward call incl. prep/reduce; packed / pipelined): B = 1024 194 / 155, B = 1536
     // 247 / 181, B = 2048 260 / 273 -- pipelined while the sample groups fill at most 3/4 of the SIMDs
     const int spw = 64 >> lane_bits(n);
@@ -241,10 +358,18 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     L.nwaves_fwd = round_waves((B + spw_packed - 1) / spw_packed);
     L.nwaves = L.lds_bwd ? B : round_waves((B + spw - 1) / spw);                      // backward partial rows
     if (L.pair) L.nwaves = (B + spw - 1) / spw;                                       // one row per workgroup (= sample group)
+    // second-generation kernels for n <= 5 (hea_zyz.hpp): the default when the shape is eligible; the first-generation
+    // variants stay selectable (qhea_set_backward_variant) and take over for shapes whose (cos, sin) table exceeds LDS
+    const int var = g_bwd_variant.load(std::memory_order_relaxed);
+    const bool zok = zyz_eligible(n, sh.E) && n != QHEA_EXP_N && (var == QHEA_BWD_AUTO || var == QHEA_BWD_ZTRI);
+    L.zfwd = zok;
+    L.ztri = zok && L.pair;
+    L.zL = zok ? zyz_layer_count(sh.runs, n) : 0;
     size_t p = kHeaderBytes;                         // WorkspaceHeader
     L.off_U = p;    p = align_up(p + (size_t)(sh.blk + 2) * n * kGateBytes);
     L.off_cs = p;   p = align_up(p + (size_t)B * sh.E * sizeof(double2));
     L.off_part = p; p = align_up(p + (size_t)L.nwaves * sh.blk * padded_3n(n) * sizeof(double));
+    L.off_rec = p;  p = align_up(p + (zok ? (size_t)(L.zL + 1) * kRecBytes : 0));
     L.total = p;
     return L;
 }
@@ -259,6 +384,41 @@ inline void profile_begin(hipStream_t st) { if (g_ev_start) (void)hipEventRecord
 inline void profile_end(hipStream_t st) {
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, st);
     g_ev_start = nullptr; g_ev_stop = nullptr;
+}
+
+int launch_prep_zyz(int n, const Shape& sh, const double* w, char* ws, const Layout& L, hipStream_t st) {
+    hipLaunchKernelGGL(prep_zyz_kernel, dim3((unsigned)(L.zL + 1)), dim3(64), 0, st, sh.runs, n, L.zL, w,
+                       ws + L.off_rec, reinterpret_cast<WorkspaceHeader*>(ws));
+    return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+}
+int launch_zyz_forward(int n, const Shape& sh, int64_t B, const Layout& L, char* ws, const AngleSrc& src, double off, double co,
+                       const double* diag, int pauli, double* out, double* state_out, const double* bias, hipStream_t st) {
+    const ZFwdArgs za{sh.runs, (long)B, (int)sh.E, ws + L.off_rec, (int)((L.zL + 1) * kRecBytes), L.zL, src, off, co, diag,
+                      pauli, out, state_out, bias};
+    const dim3 grid((unsigned)(L.nwaves_fwd / kWaves));
+    const size_t dyn = (size_t)kWaves * (64 >> n) * sh.E * sizeof(double2);
+    switch (n) {
+#define QHEA_CASE(NN) case NN: launch_fwd_zyz_##NN(grid, dyn, st, za); break;
+        QHEA_FOR_EACH_ZN(QHEA_CASE)
+#undef QHEA_CASE
+        default: return QHEA_EUNSUPPORTED;
+    }
+    return QHEA_OK;
+}
+int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char* ws, const AngleSrc& src, double off,
+                        double co, const double* diag, int pauli, const double* g, const double* state_in, const double* y,
+                        const double* bias, double inv_bt, double* out, double* grad_x, double* partial, hipStream_t st) {
+    const ZBwdArgs za{sh.runs, (long)B, (int)sh.E, (int)sh.blk, ws + L.off_rec, (int)((L.zL + 1) * kRecBytes), L.zL, src, off, co,
+                      diag, pauli, g, state_in, y, bias, inv_bt, out, grad_x, partial,
+                      &reinterpret_cast<WorkspaceHeader*>(ws)->status};
+    const size_t dyn = (size_t)(64 >> n) * sh.E * sizeof(double2);
+    switch (n) {
+#define QHEA_CASE(NN) case NN: launch_bwd_ztri_##NN(dim3((unsigned)L.nwaves), dyn, st, za); break;
+        QHEA_FOR_EACH_ZN(QHEA_CASE)
+#undef QHEA_CASE
+        default: return QHEA_EUNSUPPORTED;
+    }
+    return QHEA_OK;
 }
 
 int launch_prep(int n, const Shape& sh, int64_t B, const double* w, const double* x, char* ws, const Layout& L,
@@ -277,12 +437,6 @@ int launch_prep(int n, const Shape& sh, int64_t B, const double* w, const double
 // model-level (fused) path: frequency layers + sincos in prep, MSE residual in the circuit
 // kernel, every parameter gradient in one reduce launch
 // ---------------------------------------------------------------------------------------
-struct EncSeg {                 // x[b, col0 + e] = in[b, e % width] * w[e] + bias[e]   (or * scale when w == NULL)
-    const double* in; const double* w; const double* b;
-    double scale; int width; int ncols;
-};
-struct EncDesc { EncSeg seg[2]; };
-
 __global__ void prep_model_kernel(int n, int blk, const double* __restrict__ w, double4* __restrict__ gates,
                                   long B, int E, EncDesc enc, double2* __restrict__ cs, WorkspaceHeader* hdr) {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -333,7 +487,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         int n, int blk, int kw, long nwaves, const double* __restrict__ partial, const double* w,
         long B, int E, EncDesc enc, const double* __restrict__ grad_x, const double* __restrict__ pred,
         const double* __restrict__ y, double inv_bt, GradMap gm, int nb_w, int nb_x, double* __restrict__ grad,
-        AdamArgs adam, const WorkspaceHeader* __restrict__ hdr) {
+        AdamArgs adam, const WorkspaceHeader* __restrict__ hdr, int zyz) {
     __shared__ double acc[kRedThreads];
     __shared__ double acc2[kRedThreads];
     const int bid = blockIdx.x;
@@ -341,7 +495,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
     const double kNaN = std::numeric_limits<double>::quiet_NaN();
     if (poisoned) adam.p = nullptr;
     if (bid < nb_w) {
-        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, poisoned, &adam, gm.off_ans);
+        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, poisoned, zyz != 0, &adam, gm.off_ans);
     } else if (bid < nb_w + nb_x) {
         const int j = threadIdx.x % kFreqCols, slice = threadIdx.x / kFreqCols;
         const int e = (bid - nb_w) * kFreqCols + j;
@@ -540,7 +694,7 @@ int qhea_profile_next_circuit_kernel(void* start_event, void* stop_event) {
 }
 
 int qhea_set_backward_variant(int variant) {
-    if (variant < QHEA_BWD_AUTO || variant > QHEA_BWD_TRI) return QHEA_EINVAL;
+    if (variant < QHEA_BWD_AUTO || variant > QHEA_BWD_ZTRI) return QHEA_EINVAL;
     g_bwd_variant.store(variant, std::memory_order_relaxed);
     return QHEA_OK;
 }
@@ -584,6 +738,16 @@ int qhea_forward(int n_qubits, int n_blocks, const int32_t* enc_per_block, const
     if (!workspace || workspace_bytes < L.total) return QHEA_EWORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(workspace);
+    if (L.zfwd) {
+        rc = launch_prep_zyz(n_qubits, sh, w, ws, L, st);
+        if (rc != QHEA_OK) return rc;
+        profile_begin(st);
+        rc = launch_zyz_forward(n_qubits, sh, batch, L, ws, AngleSrc{x, EncDesc{}}, ham_offset, ham_coeff, ham_diag, ham_pauli,
+                                out, state_out, nullptr, st);
+        profile_end(st);
+        if (rc != QHEA_OK) return rc;
+        return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+    }
     rc = launch_prep(n_qubits, sh, batch, w, x, ws, L, st);
     if (rc != QHEA_OK) return rc;
     const dim3 grid((unsigned)(L.nwaves_fwd / kWaves));
@@ -624,13 +788,31 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
     const Layout L = make_layout(n_qubits, sh, batch);
     if (!workspace || workspace_bytes < L.total) return QHEA_EWORKSPACE;
     char* ws = static_cast<char*>(workspace);
+    double* partial = reinterpret_cast<double*>(ws + L.off_part);
+    if (L.ztri) {
+        rc = launch_prep_zyz(n_qubits, sh, w, ws, L, st);
+        if (rc != QHEA_OK) return rc;
+        profile_begin(st);
+        rc = launch_zyz_backward(n_qubits, sh, batch, L, ws, AngleSrc{x, EncDesc{}}, ham_offset, ham_coeff, ham_diag, ham_pauli,
+                                 g, state_in, nullptr, nullptr, 0.0, out, grad_x, partial, st);
+        profile_end(st);
+        if (rc != QHEA_OK) return rc;
+        if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
+        if (sh.blk > 0) {
+            const int kw = padded_3n(n_qubits);
+            const long ncols = sh.blk * kw;
+            hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((ncols + red_cols(kw) - 1) / red_cols(kw))), dim3(kRedThreads), 0, st,
+                               n_qubits, (int)sh.blk, kw, L.nwaves, partial, w, grad_w,
+                               reinterpret_cast<const WorkspaceHeader*>(ws), 1);
+        }
+        return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+    }
     rc = launch_prep(n_qubits, sh, batch, w, x, ws, L, st);
     if (rc != QHEA_OK) return rc;
     const dim3 grid((unsigned)(L.nwaves / kWaves));
     const double2* cs = reinterpret_cast<const double2*>(ws + L.off_cs);
     const char* gates = ws + L.off_U;
     const int gates_bytes = (int)((sh.blk + 2) * n_qubits * kGateBytes);
-    double* partial = reinterpret_cast<double*>(ws + L.off_part);
     const BwdArgs ba{sh.runs, (long)batch, (int)sh.E, (int)sh.blk, cs, gates, gates_bytes, ham_offset, ham_coeff, ham_diag, g,
                      state_in, nullptr, nullptr, 0.0, out, grad_x, partial, ham_pauli, use_tri(),
                      L.nwaves > simd_count() ? 1 : 0, &reinterpret_cast<WorkspaceHeader*>(ws)->status};
@@ -649,7 +831,7 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
         const long ncols = sh.blk * padded_3n(n_qubits);
         hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((ncols + red_cols(padded_3n(n_qubits)) - 1) / red_cols(padded_3n(n_qubits)))), dim3(kRedThreads), 0, st,
                            n_qubits, (int)sh.blk, padded_3n(n_qubits), L.nwaves, partial, w, grad_w,
-                           reinterpret_cast<const WorkspaceHeader*>(ws));
+                           reinterpret_cast<const WorkspaceHeader*>(ws), 0);
     }
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
@@ -680,6 +862,16 @@ int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double*
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(workspace);
     const EncDesc enc = make_enc(desc, mi, branch, trunk, params);
+    if (M.L.zfwd) {
+        rc = launch_prep_zyz(mi.n, mi.sh, params + mi.off_ans, ws, M.L, st);
+        if (rc != QHEA_OK) return rc;
+        profile_begin(st);
+        rc = launch_zyz_forward(mi.n, mi.sh, batch, M.L, ws, AngleSrc{nullptr, enc}, desc->ham_offset, desc->ham_coeff, ham_diag,
+                                desc->ham_pauli, pred, nullptr, mi.has_bias ? params + mi.off_bias : nullptr, st);
+        profile_end(st);
+        if (rc != QHEA_OK) return rc;
+        return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+    }
     rc = launch_prep_model(mi, batch, params, enc, ws, M.L, st);
     if (rc != QHEA_OK) return rc;
     const dim3 grid((unsigned)(M.L.nwaves_fwd / kWaves));
@@ -716,12 +908,33 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
     if (!workspace || workspace_bytes < M.total) return QHEA_EWORKSPACE;
     char* ws = static_cast<char*>(workspace);
     const EncDesc enc = make_enc(desc, mi, branch, trunk, params);
-    rc = launch_prep_model(mi, batch, params, enc, ws, M.L, st);
-    if (rc != QHEA_OK) return rc;
-    const dim3 grid((unsigned)(M.L.nwaves / kWaves));
     double* gx = reinterpret_cast<double*>(ws + M.off_gx);
     double* pr = pred ? pred : reinterpret_cast<double*>(ws + M.off_pred);
     double* partial = reinterpret_cast<double*>(ws + M.L.off_part);
+    GradMap gm{};
+    gm.off_ans = mi.off_ans; gm.off_bias = mi.off_bias; gm.off_sse = mi.P;
+    for (int s = 0; s < 2; ++s) { gm.off_w[s] = mi.off_w[s]; gm.off_b[s] = mi.off_b[s]; }
+    const int kw = padded_3n(mi.n);
+    const int nb_w = (int)((mi.sh.blk * kw + red_cols(kw) - 1) / red_cols(kw));
+    const int nb_x = mi.trainable ? (int)((mi.sh.E + kFreqCols - 1) / kFreqCols) : 0;
+    if (M.L.ztri) {
+        rc = launch_prep_zyz(mi.n, mi.sh, params + mi.off_ans, ws, M.L, st);
+        if (rc != QHEA_OK) return rc;
+        profile_begin(st);
+        rc = launch_zyz_backward(mi.n, mi.sh, batch, M.L, ws, AngleSrc{nullptr, enc}, desc->ham_offset, desc->ham_coeff, ham_diag,
+                                 desc->ham_pauli, nullptr, nullptr, y, mi.has_bias ? params + mi.off_bias : nullptr,
+                                 inv_batch_total, pr, gx, partial, st);
+        profile_end(st);
+        if (rc != QHEA_OK) return rc;
+        if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
+        hipLaunchKernelGGL(reduce_model_kernel, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
+                           (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
+                           gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws), 1);
+        return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+    }
+    rc = launch_prep_model(mi, batch, params, enc, ws, M.L, st);
+    if (rc != QHEA_OK) return rc;
+    const dim3 grid((unsigned)(M.L.nwaves / kWaves));
     const BwdArgs ba{mi.sh.runs, (long)batch, (int)mi.sh.E, (int)mi.sh.blk,
                      reinterpret_cast<const double2*>(ws + M.L.off_cs), ws + M.L.off_U,
                      (int)((mi.sh.blk + 2) * mi.n * kGateBytes), desc->ham_offset, desc->ham_coeff, ham_diag,
@@ -739,15 +952,9 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
     }
     profile_end(st);
     if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
-    GradMap gm{};
-    gm.off_ans = mi.off_ans; gm.off_bias = mi.off_bias; gm.off_sse = mi.P;
-    for (int s = 0; s < 2; ++s) { gm.off_w[s] = mi.off_w[s]; gm.off_b[s] = mi.off_b[s]; }
-    const int kw = padded_3n(mi.n);
-    const int nb_w = (int)((mi.sh.blk * kw + red_cols(kw) - 1) / red_cols(kw));
-    const int nb_x = mi.trainable ? (int)((mi.sh.E + kFreqCols - 1) / kFreqCols) : 0;
     hipLaunchKernelGGL(reduce_model_kernel, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
                        (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
-                       gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws));
+                       gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws), 0);
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 

@@ -45,6 +45,15 @@ struct Runs {
     int ld[kMaxRuns];
 };
 
+// Frequency layers of the model-level calls (core/models_pt.py:14-68): encoding column e of segment `seg` is
+//   x[b, e] = in[b, e % width] * w[e] + b[e]      (_TiledElementWise)     or     in[b, e % width] * scale   (w == NULL: _ScaleRepeat)
+// segment 0 = trunk (QuanONet) / the only input (HEAQNN), segment 1 = branch; columns trunk first.
+struct EncSeg {
+    const double* in; const double* w; const double* b;
+    double scale; int width; int ncols;
+};
+struct EncDesc { EncSeg seg[2]; };
+
 // Layout experiment (never shipped): -DQHEA_EXP_N=5 -DQHEA_EXP_LB=4 (or 3) builds the packed
 // kernels of that qubit count with fewer lane bits and 2^(N-LB) amplitudes per lane (more samples per wave, the
 // top qubits' gates in-lane); the pipelined kernels need the all-lane layout and are compiled out of such a build.

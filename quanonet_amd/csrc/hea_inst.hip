@@ -1,6 +1,7 @@
 // hea_inst.hip -- instantiates the wave-resident forward/backward kernels for ONE qubit count
 // (compile with -DQHEA_N=<n>; one object per n keeps the build parallel).
 #include "hea_device.hpp"
+#include "hea_zyz.hpp"
 
 #ifndef QHEA_N
 #error "compile with -DQHEA_N=<qubits>"
@@ -42,5 +43,17 @@ void QHEA_CAT(launch_bwd_pair_, QHEA_N)(dim3 grid, hipStream_t st, const BwdArgs
     (void)grid; (void)st; (void)a;      // never selected for n > 5 (hea_api.hip: make_layout)
 #endif
 }
+
+#if QHEA_N <= 5 && QHEA_N != QHEA_EXP_N
+void QHEA_CAT(launch_fwd_zyz_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArgs& a) {
+    hipLaunchKernelGGL(fwd_zyz_kernel<QHEA_N>, grid, dim3(kWaves * 64), dyn_lds, st, a);
+}
+void QHEA_CAT(launch_bwd_ztri_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a) {
+    hipLaunchKernelGGL(bwd_ztri_kernel<QHEA_N>, grid, dim3(128 + 64 * kSigmaWaves), dyn_lds, st, a);
+}
+#elif QHEA_N <= 5      // layout-experiment build: the ZYZ kernels need the all-lane layout and are never selected
+void QHEA_CAT(launch_fwd_zyz_, QHEA_N)(dim3, size_t, hipStream_t, const ZFwdArgs&) {}
+void QHEA_CAT(launch_bwd_ztri_, QHEA_N)(dim3, size_t, hipStream_t, const ZBwdArgs&) {}
+#endif
 
 }  // namespace qhea

@@ -36,10 +36,11 @@ def _run(n, cfgs, x, w, g, dev, off, co, diag=None, use_state=True, pauli='Z'):
     return (out.cpu().numpy(), st.cpu().numpy(), gx.cpu().numpy(), gw.cpu().numpy(), out2.cpu().numpy())
 
 
-@pytest.fixture(params=['packed', 'pair', 'tri'])
+@pytest.fixture(params=['packed', 'pair', 'tri', 'ztri'])
 def backward_variant(request, dev):
-    """The three backward kernels for n <= 5 (one wave per sample group, the psi-wave / lambda-wave pipeline, the
-    psi / lambda / sigma three-wave pipeline), forced through qhea_set_backward_variant; afterwards the status word
+    """The backward kernels for n <= 5 (one wave per sample group, the psi-wave / lambda-wave pipeline, the
+    psi / lambda / sigma three-wave pipeline, and that pipeline on the ZYZ form of the gates -- 'ztri', which with
+    its forward kernel is what the default 'auto' runs), forced through qhea_set_backward_variant; afterwards the status word
     must be clean (no hand-off overrun) and the choice goes back to automatic."""
     from quanonet_amd import _lib
     _lib.set_backward_variant(request.param)
