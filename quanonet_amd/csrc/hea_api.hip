@@ -137,30 +137,27 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
     const int l = blockIdx.x, j = threadIdx.x;
     if (l == 0 && j == 0) header_init(hdr);
     const LayerInfo cur = decode_layer(runs, n, l < L ? l : -1), prev = decode_layer(runs, n, l - 1);
+    __shared__ GateZ gz[2][QHEA_MAX_QUBITS];           // [0]: this layer's gates, [1]: the previous layer's
+    if (j < 2 * n) {                                   // one decomposition per thread, then everybody multiplies phasors
+        const int which = j / n, q = j % n;
+        const LayerInfo& li = which ? prev : cur;
+        if (li.kind == 1) gz[which][q] = gate_zyz(w + (long)li.s * 3 * n, n, q);
+    }
+    __syncthreads();
     char* out = rec + (long)l * kRecBytes;
     if (j < (1 << n)) {
         double2 ph = make_double2(1.0, 0.0);
-        if (cur.kind == 1) {
-            for (int q = 0; q < n; ++q) {
-                const GateZ g = gate_zyz(w + (long)cur.s * 3 * n, n, q);
-                ph = cmul(ph, ((j >> q) & 1) ? cconj(g.v) : g.v);
-            }
-        }
+        if (cur.kind == 1)
+            for (int q = 0; q < n; ++q) ph = cmul(ph, ((j >> q) & 1) ? cconj(gz[0][q].v) : gz[0][q].v);
         if (prev.kind == 1) {
             const int h = ring_src_index(n, j);
-            for (int q = 0; q < n; ++q) {
-                const GateZ g = gate_zyz(w + (long)prev.s * 3 * n, n, q);
-                ph = cmul(ph, ((h >> q) & 1) ? cconj(g.u) : g.u);
-            }
+            for (int q = 0; q < n; ++q) ph = cmul(ph, ((h >> q) & 1) ? cconj(gz[1][q].u) : gz[1][q].u);
         }
         reinterpret_cast<double2*>(out)[j] = ph;
     } else if (j >= 32 && j < 32 + 2 * n) {
         const int q = (j - 32) >> 1, var = (j - 32) & 1;
         double2 e = make_double2(1.0, 0.0);
-        if (cur.kind == 1) {
-            const GateZ g = gate_zyz(w + (long)cur.s * 3 * n, n, q);
-            e = make_double2(g.c, var ? g.s : -g.s);
-        }
+        if (cur.kind == 1) e = make_double2(gz[0][q].c, var ? gz[0][q].s : -gz[0][q].s);
         *reinterpret_cast<double2*>(out + kRecRy + q * 32 + var * 16) = e;
     }
 }
@@ -369,7 +366,8 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     L.off_U = p;    p = align_up(p + (size_t)(sh.blk + 2) * n * kGateBytes);
     L.off_cs = p;   p = align_up(p + (size_t)B * sh.E * sizeof(double2));
     L.off_part = p; p = align_up(p + (size_t)L.nwaves * sh.blk * padded_3n(n) * sizeof(double));
-    L.off_rec = p;  p = align_up(p + (zok ? (size_t)(L.zL + 1) * kRecBytes : 0));
+    L.off_rec = p;  p = align_up(p + (zok ? (size_t)(L.zL + 1 + 2 * kPadRecs) * kRecBytes : 0));   // padded both sides
+    if (zok) L.off_rec += (size_t)kPadRecs * kRecBytes;                                           // -> record 0
     L.total = p;
     return L;
 }
@@ -393,8 +391,11 @@ int launch_prep_zyz(int n, const Shape& sh, const double* w, char* ws, const Lay
 }
 int launch_zyz_forward(int n, const Shape& sh, int64_t B, const Layout& L, char* ws, const AngleSrc& src, double off, double co,
                        const double* diag, int pauli, double* out, double* state_out, const double* bias, hipStream_t st) {
+    const int fast = zyz_fast_ld(sh.runs, n);
+    int nblocks = 0;
+    for (int i = 0; i < sh.runs.nruns; ++i) nblocks += sh.runs.count[i];
     const ZFwdArgs za{sh.runs, (long)B, (int)sh.E, ws + L.off_rec, (int)((L.zL + 1) * kRecBytes), L.zL, src, off, co, diag,
-                      pauli, out, state_out, bias};
+                      pauli, out, state_out, bias, fast, nblocks};
     const dim3 grid((unsigned)(L.nwaves_fwd / kWaves));
     const size_t dyn = (size_t)kWaves * (64 >> n) * sh.E * sizeof(double2);
     switch (n) {
@@ -408,9 +409,12 @@ int launch_zyz_forward(int n, const Shape& sh, int64_t B, const Layout& L, char*
 int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char* ws, const AngleSrc& src, double off,
                         double co, const double* diag, int pauli, const double* g, const double* state_in, const double* y,
                         const double* bias, double inv_bt, double* out, double* grad_x, double* partial, hipStream_t st) {
+    const int fast = zyz_fast_ld(sh.runs, n);
+    int nblocks = 0;
+    for (int i = 0; i < sh.runs.nruns; ++i) nblocks += sh.runs.count[i];
     const ZBwdArgs za{sh.runs, (long)B, (int)sh.E, (int)sh.blk, ws + L.off_rec, (int)((L.zL + 1) * kRecBytes), L.zL, src, off, co,
                       diag, pauli, g, state_in, y, bias, inv_bt, out, grad_x, partial,
-                      &reinterpret_cast<WorkspaceHeader*>(ws)->status};
+                      &reinterpret_cast<WorkspaceHeader*>(ws)->status, fast, nblocks};
     const size_t dyn = (size_t)(64 >> n) * sh.E * sizeof(double2);
     switch (n) {
 #define QHEA_CASE(NN) case NN: launch_bwd_ztri_##NN(dim3((unsigned)L.nwaves), dyn, st, za); break;

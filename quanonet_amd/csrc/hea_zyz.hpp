@@ -89,22 +89,42 @@ __device__ __forceinline__ void apply_ry(double& re, double& im, const double2& 
     im = u.x * im + sv * qi;
 }
 
-// Layer records stream: global -> two stage registers (prefetch distance two layers) -> two-slot wave-private LDS
-// ring -> this lane's coefficients, read one layer ahead.
+// Layer records stream: global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: every lane's 16 bytes land at
+// M0 + 16 * lane, no VGPR staging, no ds_write) into a wave-private ring of kSlots records, kDist records ahead of the
+// one being worked on; this lane's coefficients are then read one layer ahead into registers.  A layer of the ZYZ
+// form is only ~300-400 clocks long, so the one-layer prefetch distance of the first-generation GateStream (two
+// stage registers) left the global-load latency exposed at every layer (measured: half of the wave's cycles waiting).
+// The DMA and its wait are inline assembly: behind the builtin form the compiler cannot tell which ring slot a
+// ds_read touches and drains vmcnt to 0 before every LDS read.  The wave's in-order vmcnt makes the counted wait
+// exact: after issuing record l + kDist*D, `vmcnt(kDist-1)` leaves only the kDist-1 youngest in flight, so record
+// l + D has landed.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma_record(const u32x4& rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+template <int CNT>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CNT) : "memory"); }
+
+constexpr int kSlots = 8, kDist = 6;
+constexpr int kRecRingBytes = kSlots * kRecBytes;           // per streaming wave
+
 template <int N>
 struct LayerStream {
-    rsrc_t rsrc;
-    char* ring;                 // 2 x kRecBytes, wave-private
+    u32x4 rsrc;
+    char* ring;                 // kSlots x kRecBytes, wave-private
+    unsigned lds0;              // its LDS byte address (wave-uniform)
     unsigned lane16, dgoff;
     unsigned voff[N];
     int L;                      // records 0 .. L
-    u32x4 st0, st1;             // record r travels in st[r & 1]
     double2 dg;                 // diagonal entry to apply next
     double2 ry[N];              // RY coefficients of the ansatz layer they were last read for
 
     __device__ __forceinline__ void init(const char* table, int bytes, char* ring_wave, int lane, int klow, int nlayers) {
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(table), 0, bytes, 0x00020000);
+        const unsigned long long base = reinterpret_cast<unsigned long long>(table);
+        rsrc = u32x4{(unsigned)base, (unsigned)(base >> 32) & 0xffffu, (unsigned)bytes, 0x00020000u};
         ring = ring_wave;
+        lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring_wave;
         lane16 = (unsigned)lane * 16u;
         dgoff = (unsigned)klow * 16u;
         L = nlayers;
@@ -113,31 +133,32 @@ struct LayerStream {
             voff[Q] = kRecRy + Q * 32 + (((unsigned)lane >> Q) & 1u) * 16u;
         });
     }
-    __device__ __forceinline__ u32x4 gload(int l) const {
-        l = l < 0 ? 0 : (l > L ? L : l);
-        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, l * kRecBytes, 0);
+    __device__ __forceinline__ void issue(int l) const {           // records outside [0, L] repeat an end record (never read)
+        const int lc = l < 0 ? 0 : (l > L ? L : l);
+        dma_record(rsrc, lds0 + (unsigned)(l & (kSlots - 1)) * kRecBytes, lane16, (unsigned)lc * kRecBytes);
     }
-    __device__ __forceinline__ char* buf(int l) const { return ring + ((l & 1) ? kRecBytes : 0); }
-    __device__ __forceinline__ void park_and_fetch(int lp, int lf) {        // record lp: stage -> LDS; fetch record lf (same parity)
-        if (lp & 1) { *reinterpret_cast<u32x4*>(buf(lp) + lane16) = st1; st1 = gload(lf); }
-        else        { *reinterpret_cast<u32x4*>(buf(lp) + lane16) = st0; st0 = gload(lf); }
-    }
+    __device__ __forceinline__ char* buf(int l) const { return ring + (l & (kSlots - 1)) * kRecBytes; }
     __device__ __forceinline__ double2 rd_diag(int l) const { return *reinterpret_cast<const double2*>(buf(l) + dgoff); }
     template <int Q>
     __device__ __forceinline__ double2 rd_ry(int l) const { return *reinterpret_cast<const double2*>(buf(l) + voff[Q]); }
     __device__ __forceinline__ void rd_all_ry(int l) { static_for<0, N>([&](auto q) { ry[decltype(q)::value] = rd_ry<decltype(q)::value>(l); }); }
 
-    // walk with step D = +1 (forward) / -1 (reverse) starting at record l0: l0 parked and read, l0 + D and l0 + 2D in flight
+    // walk with step D = +1 (forward) / -1 (reverse) starting at record l0: on return l0 has landed and been read,
+    // l0 + D .. l0 + (kDist-1) D are in flight
     template <int D>
     __device__ __forceinline__ void prime(int l0) {
-        if (l0 & 1) { st1 = gload(l0); *reinterpret_cast<u32x4*>(buf(l0) + lane16) = st1; st1 = gload(l0 + 2 * D); st0 = gload(l0 + D); }
-        else        { st0 = gload(l0); *reinterpret_cast<u32x4*>(buf(l0) + lane16) = st0; st0 = gload(l0 + 2 * D); st1 = gload(l0 + D); }
+#pragma unroll
+        for (int i = 0; i < kDist; ++i) issue(l0 + i * D);
+        wait_vmcnt<kDist - 1>();
         dg = rd_diag(l0);
         rd_all_ry(l0);
     }
-    // top of the step that works on record l: bring record l + D into LDS, fetch record l + 3D
+    // top of the step that works on record l: record l + D has landed when this returns
     template <int D>
-    __device__ __forceinline__ void begin(int l) { park_and_fetch(l + D, l + 3 * D); }
+    __device__ __forceinline__ void begin(int l) {
+        issue(l + kDist * D);
+        wait_vmcnt<kDist - 1>();
+    }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -194,14 +215,133 @@ __device__ __forceinline__ void zyz_forward(double (&re)[1], double (&im)[1], co
     apply_phase<false>(re[0], im[0], ls.dg);          // record L: what is still pending after the last layer
 }
 
+// ---------------------------------------------------------------------------------------
+// Block-unrolled fast path.  Every circuit the reference builds has blocks of ONE RX chunk (0 < enc <= n) followed
+// by the same number LD of sub-layers (1 or 2: every script uses 2, the shipped Q2 checkpoint 1).  For those the
+// layer loop is unrolled over a whole block: a block's 1 + LD records are fetched together (kBDist blocks ahead),
+// every coefficient lives in a register of its own that is refilled with the NEXT block's value right after its last
+// use, and the per-layer bookkeeping of the generic walk (slot arithmetic, clamping, kind tests: ~25 scalar and ~8
+// address instructions per layer, which cost a lone wave as much issue time as arithmetic does) is paid once per block.
+// Other shapes take the generic layer walk above.  The record table is padded on both sides (kPadRecs records,
+// never written, never used in arithmetic), so the fetches at the ends need no clamping.
+// ---------------------------------------------------------------------------------------
+constexpr int kBSlots = 4, kBDist = 2;         // block slots per ring; blocks in flight beyond the one being read
+constexpr int kPadRecs = 9;                    // >= (kBDist + 1) * 3 records of padding before record 0 and after record L
+constexpr int kBlockRingBytes = kBSlots * 3 * kRecBytes;     // per streaming wave (LD = 2)
+
+template <int N, int LD>
+struct BlockStream {
+    static constexpr int RPB = 1 + LD;
+    u32x4 rsrc;                 // starts kPadRecs records before record 0
+    char* ring;
+    unsigned lds0, lane16, a_dg;
+    unsigned a_ry[N];
+    double2 dg[RPB];            // diagonals of the records of the block at hand
+    double2 ry[LD][N];          // its RY coefficients (this lane's variants)
+    double2 cs[N];              // its RX (cos, sin)
+
+    __device__ __forceinline__ void init(const char* rec0, int nrec /* L + 1 */, char* ring_wave, int lane, int klow) {
+        const unsigned long long base = reinterpret_cast<unsigned long long>(rec0) - (unsigned long long)kPadRecs * kRecBytes;
+        rsrc = u32x4{(unsigned)base, (unsigned)(base >> 32) & 0xffffu, (unsigned)((nrec + 2 * kPadRecs) * kRecBytes), 0x00020000u};
+        ring = ring_wave;
+        lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring_wave;
+        lane16 = (unsigned)lane * 16u;
+        a_dg = (unsigned)klow * 16u;
+        static_for<0, N>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            a_ry[Q] = kRecRy + Q * 32 + (((unsigned)lane >> Q) & 1u) * 16u;
+        });
+    }
+    __device__ __forceinline__ void issue(int b) const {             // b in [-(kBDist+1), nblocks + kBDist + 1]
+        const unsigned slot = lds0 + (unsigned)(b & (kBSlots - 1)) * (RPB * kRecBytes);
+        const unsigned soff = (unsigned)((b * RPB + kPadRecs) * kRecBytes);
+#pragma unroll
+        for (int i = 0; i < RPB; ++i) dma_record(rsrc, slot + i * kRecBytes, lane16, soff + i * kRecBytes);
+    }
+    __device__ __forceinline__ const char* slot(int b) const { return ring + (b & (kBSlots - 1)) * (RPB * kRecBytes); }
+    template <int D>
+    __device__ __forceinline__ void step(int b) const {              // block b + D has landed when this returns
+        issue(b + (kBDist + 1) * D);
+        wait_vmcnt<kBDist * RPB>();
+    }
+    static __device__ __forceinline__ double2 rd(const char* p, unsigned off) { return *reinterpret_cast<const double2*>(p + off); }
+    __device__ __forceinline__ void load_records(const char* sl) {
+#pragma unroll
+        for (int i = 0; i < RPB; ++i) dg[i] = rd(sl, i * kRecBytes + a_dg);
+#pragma unroll
+        for (int s = 0; s < LD; ++s)
+            static_for<0, N>([&](auto q) { ry[s][decltype(q)::value] = rd(sl, (1 + s) * kRecBytes + a_ry[decltype(q)::value]); });
+    }
+    __device__ __forceinline__ void load_cs(const double2* __restrict__ csrow, int c0, int E) {
+        static_for<0, N>([&](auto q) {
+            const int e = c0 + decltype(q)::value;
+            cs[decltype(q)::value] = csrow[e < 0 ? 0 : (e < E ? e : E - 1)];
+        });
+    }
+};
+
+__host__ __device__ inline int zyz_fast_ld(const Runs& r, int n) {      // LD of the fast path, 0 = not applicable
+    if (r.nruns < 1) return 0;
+    const int ld = r.ld[0];
+    if (ld != 1 && ld != 2) return 0;
+    for (int i = 0; i < r.nruns; ++i)
+        if (r.ld[i] != ld || r.enc[i] < 1 || r.enc[i] > n || r.count[i] < 1) return 0;
+    return ld;
+}
+
+template <int N, int LD>
+__device__ __forceinline__ void zyz_forward_fast(double (&re)[1], double (&im)[1], const Runs& runs, BlockStream<N, LD>& bs,
+                                                 const double2* __restrict__ csrow, int E, int lane, int klow, int ring_fwd) {
+    constexpr int RPB = 1 + LD;
+    re[0] = klow == 0 ? 1.0 : 0.0;
+    im[0] = 0.0;
+#pragma unroll
+    for (int i = 0; i <= kBDist; ++i) bs.issue(i);
+    wait_vmcnt<kBDist * RPB>();
+    bs.load_records(bs.slot(0));
+    bs.load_cs(csrow, 0, E);
+    int b = 0, col = 0;
+    for (int ri = 0; ri < runs.nruns; ++ri) {
+        const int m = runs.enc[ri];
+        for (int rep = 0; rep < runs.count[ri]; ++rep) {
+            bs.template step<1>(b);
+            const char* nx = bs.slot(b + 1);
+            apply_phase<false>(re[0], im[0], bs.dg[0]);
+            bs.dg[0] = bs.rd(nx, bs.a_dg);
+            for_gates_below<N>(m, [&](auto q) {
+                constexpr int Q = decltype(q)::value;
+                apply_rx<N, Q>(re, im, bs.cs[Q].x, bs.cs[Q].y);
+            });
+            col += m;
+            bs.load_cs(csrow, col, E);
+#pragma unroll
+            for (int s = 0; s < LD; ++s) {
+                apply_phase<false>(re[0], im[0], bs.dg[1 + s]);
+                bs.dg[1 + s] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_dg);
+                static_for<0, N>([&](auto q) {
+                    constexpr int Q = decltype(q)::value;
+                    apply_ry<Q, false>(re[0], im[0], bs.ry[s][Q]);
+                    bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
+                });
+                re[0] = lane_gather(re[0], ring_fwd);
+                im[0] = lane_gather(im[0], ring_fwd);
+            }
+            ++b;
+        }
+    }
+    apply_phase<false>(re[0], im[0], bs.dg[0]);        // record L = record 0 of the slot after the last block
+}
+
 struct ZFwdArgs {
     Runs runs; long B; int E; const char* rec; int rec_bytes; int L; AngleSrc src; double off, co;
     const double* diag; int pauli; double* out; double* state_out; const double* bias;
+    int fast_ld, nblocks;       // block-unrolled fast path: sub-layers per block (0 = generic walk), number of blocks
 };
 struct ZBwdArgs {
     Runs runs; long B; int E; int blk; const char* rec; int rec_bytes; int L; AngleSrc src; double off, co;
     const double* diag; int pauli; const double* g; const double* state_in; const double* y; const double* bias;
     double inv_bt; double* out; double* grad_x; double* partial; int* status;
+    int fast_ld, nblocks;
 };
 
 template <int N>
@@ -209,7 +349,7 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_zyz_kernel(ZFwdArgs a) {
     using C = Cfg<N>;
     static_assert(C::R == 1, "all-lane layout");
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // kWaves x SPW x E (cos, sin)
-    __shared__ __attribute__((aligned(16))) char rec_ring[kWaves * 2 * kRecBytes];
+    __shared__ __attribute__((aligned(16))) char rec_ring[kWaves * kBlockRingBytes];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long wave = (long)blockIdx.x * kWaves + wib;
@@ -221,11 +361,22 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_zyz_kernel(ZFwdArgs a) {
 
     double2* cs = reinterpret_cast<double2*>(dyn_lds) + (long)wib * C::SPW * a.E;
     fill_cs(cs, a.src, a.E, wave * C::SPW, a.B, C::SPW, lane, 64);                // wave-private: LDS is in-order per wave
-    LayerStream<N> ls;
-    ls.init(a.rec, a.rec_bytes, rec_ring + wib * 2 * kRecBytes, lane, klow, a.L);
-
+    const double2* csrow = cs + (lane >> C::LB) * a.E;
+    char* my_ring = rec_ring + wib * kBlockRingBytes;
     double re[1], im[1];
-    zyz_forward<N>(re, im, a.runs, ls, cs + (lane >> C::LB) * a.E, a.E, lane, klow, ring_fwd);
+    if (a.fast_ld == 2) {
+        BlockStream<N, 2> bs;
+        bs.init(a.rec, a.L + 1, my_ring, lane, klow);
+        zyz_forward_fast<N, 2>(re, im, a.runs, bs, csrow, a.E, lane, klow, ring_fwd);
+    } else if (a.fast_ld == 1) {
+        BlockStream<N, 1> bs;
+        bs.init(a.rec, a.L + 1, my_ring, lane, klow);
+        zyz_forward_fast<N, 1>(re, im, a.runs, bs, csrow, a.E, lane, klow, ring_fwd);
+    } else {
+        LayerStream<N> ls;
+        ls.init(a.rec, a.rec_bytes, my_ring, lane, klow, a.L);
+        zyz_forward<N>(re, im, a.runs, ls, csrow, a.E, lane, klow, ring_fwd);
+    }
 
     if (a.state_out && valid)
         reinterpret_cast<double2*>(a.state_out)[(b << N) + klow] = make_double2(re[0], im[0]);
@@ -239,89 +390,124 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_zyz_kernel(ZFwdArgs a) {
 // psi / lambda / sigma pipelined backward kernel, ZYZ form.  Roles, rings, counters and failure reporting as in
 // bwd_tri_kernel (hea_device.hpp); a "step" is one layer (one ansatz sub-layer or one RX chunk).
 // ---------------------------------------------------------------------------------------
-template <int N>
-__global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_ztri_kernel(ZBwdArgs a) {
+// One chain wave of the pipelined backward kernel: role 0 = psi (forward sweep or state_in, then psi walked back),
+// role 1 = lambda (lambda_N = g H psi_N, walked back).  MODE 0: generic layer walk; 1 / 2: block-unrolled fast path
+// with that many sub-layers per block.  Publishing protocol as in bwd_tri_kernel (hea_device.hpp).
+template <int N, int MODE>
+__device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane, int klow, bool valid, long b,
+                                           const double2* cs, char* my_ring, double2 (*psi_ring)[64],
+                                           double2 (*lam_ring)[64], double2* psi_final, TriSync* sync) {
     using C = Cfg<N>;
-    static_assert(C::R == 1 && kSigmaWaves == 2, "all-lane layout, two sigma waves");
-    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // SPW x E (cos, sin)
-    __shared__ __attribute__((aligned(16))) char rec_ring[2 * 2 * kRecBytes];
-    __shared__ double2 psi_ring[kPairRing][64];
-    __shared__ double2 lam_ring[kPairRing][64];
-    __shared__ double2 psi_final[64];
-    __shared__ TriSync sync;
-
-    const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0: psi, 1: lambda, 2..: sigma
-    const long wave = blockIdx.x;                                                 // one sample group per workgroup
-    const long b_raw = wave * C::SPW + (lane >> C::LB);
-    const bool valid = b_raw < a.B;
-    const long b = valid ? b_raw : a.B - 1;
-    const int klow = lane & (C::LANES - 1);
+    __builtin_amdgcn_s_setprio(3);                          // the chains are the critical path (hea_device.hpp)
     const int E = a.E;
-
-    if (threadIdx.x == 0) {
-        sync.psi_prod = 0; sync.lam_prod = 0; sync.ready = 0; sync.abort = 0;
-        for (int w = 0; w < kSigmaWaves; ++w) sync.cursor[w] = w;
-    }
-    double2* cs = reinterpret_cast<double2*>(dyn_lds);
-    fill_cs(cs, a.src, E, wave * C::SPW, a.B, C::SPW, (int)threadIdx.x, 128 + 64 * kSigmaWaves);   // all four waves
-    __syncthreads();
-
-    if (role < 2) {
-        // ------------------------------------------------------------------ psi / lambda chains
-        __builtin_amdgcn_s_setprio(3);
-        const int ring_fwd = ring_source<N>(lane, false);
-        const int ring_rev = ring_source<N>(lane, true);
-        const double2* csrow = cs + (lane >> C::LB) * E;
-        LayerStream<N> ls;
-        ls.init(a.rec, a.rec_bytes, rec_ring + role * 2 * kRecBytes, lane, klow, a.L);
-        double sr[1], si[1];
-        int seen[kSigmaWaves];
+    const int ring_fwd = ring_source<N>(lane, false);
+    const int ring_rev = ring_source<N>(lane, true);
+    const double2* csrow = cs + (lane >> C::LB) * E;
+    LayerStream<N> ls;
+    BlockStream<N, MODE == 0 ? 1 : MODE> bs;
+    if constexpr (MODE == 0) ls.init(a.rec, a.rec_bytes, my_ring, lane, klow, a.L);
+    else bs.init(a.rec, a.L + 1, my_ring, lane, klow);
+    double sr[1], si[1];
+    int seen[kSigmaWaves];
 #pragma unroll
-        for (int w = 0; w < kSigmaWaves; ++w) seen[w] = 0;
-        if (role == 0) {
-            if (a.state_in) {
-                const double2 s0 = reinterpret_cast<const double2*>(a.state_in)[(b << N) + klow];
-                sr[0] = s0.x; si[0] = s0.y;
-            } else {
-                zyz_forward<N>(sr, si, a.runs, ls, csrow, E, lane, klow, ring_fwd);
-            }
-            psi_final[lane] = make_double2(sr[0], si[0]);
-            __hip_atomic_store(&sync.ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int w = 0; w < kSigmaWaves; ++w) seen[w] = 0;
+    if (role == 0) {
+        if (a.state_in) {
+            const double2 s0 = reinterpret_cast<const double2*>(a.state_in)[(b << N) + klow];
+            sr[0] = s0.x; si[0] = s0.y;
         } else {
-            int seen_ready = 0;
-            pair_wait_ge(&sync.ready, 1, &sync.abort, seen_ready);
-            double fr[1] = {psi_final[lane].x}, fi[1] = {psi_final[lane].y};
-            basis_change<N, false>(fr, fi, a.pauli, lane);
-            const double h = ham_weight<N>(klow, a.off, a.co, a.diag);
-            double gb;
-            {
-                double v[1] = {h * (fr[0] * fr[0] + fi[0] * fi[0])};
-                lane_reduce<1, C::LB>(v, lane);
-                const double pred = v[0] + (a.bias ? a.bias[0] : 0.0);
-                if (a.out && valid && klow == 0) a.out[b] = pred;
-                gb = a.y ? 2.0 * (pred - a.y[b]) * a.inv_bt : a.g[b];
-            }
-            if (!valid) gb = 0.0;
-            sr[0] = gb * h * fr[0]; si[0] = gb * h * fi[0];
-            basis_change<N, true>(sr, si, a.pauli, lane);
+            if constexpr (MODE == 0) zyz_forward<N>(sr, si, a.runs, ls, csrow, E, lane, klow, ring_fwd);
+            else zyz_forward_fast<N, MODE>(sr, si, a.runs, bs, csrow, E, lane, klow, ring_fwd);
         }
-        double2 (*ring)[64] = role == 0 ? psi_ring : lam_ring;
-        int* prod = role == 0 ? &sync.psi_prod : &sync.lam_prod;
-        int step = 0;
-        auto publish = [&]() {
-            if (step >= kPairRing) {
+        psi_final[lane] = make_double2(sr[0], si[0]);
+        __hip_atomic_store(&sync->ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        int seen_ready = 0;
+        pair_wait_ge(&sync->ready, 1, &sync->abort, seen_ready);
+        double fr[1] = {psi_final[lane].x}, fi[1] = {psi_final[lane].y};
+        basis_change<N, false>(fr, fi, a.pauli, lane);
+        const double h = ham_weight<N>(klow, a.off, a.co, a.diag);
+        double gb;
+        {
+            double v[1] = {h * (fr[0] * fr[0] + fi[0] * fi[0])};
+            lane_reduce<1, C::LB>(v, lane);
+            const double pred = v[0] + (a.bias ? a.bias[0] : 0.0);
+            if (a.out && valid && klow == 0) a.out[b] = pred;
+            gb = a.y ? 2.0 * (pred - a.y[b]) * a.inv_bt : a.g[b];
+        }
+        if (!valid) gb = 0.0;
+        sr[0] = gb * h * fr[0]; si[0] = gb * h * fi[0];
+        basis_change<N, true>(sr, si, a.pauli, lane);
+    }
+    double2 (*ring)[64] = role == 0 ? psi_ring : lam_ring;
+    int* prod = role == 0 ? &sync->psi_prod : &sync->lam_prod;
+    int step = 0;
+    auto publish = [&]() {
+        if (step >= kPairRing) {
 #pragma unroll
-                for (int w = 0; w < kSigmaWaves; ++w)
-                    pair_wait_ge(&sync.cursor[w], step - kPairRing + 1, &sync.abort, seen[w]);
+            for (int w = 0; w < kSigmaWaves; ++w)
+                pair_wait_ge(&sync->cursor[w], step - kPairRing + 1, &sync->abort, seen[w]);
+        }
+        ring[step & (kPairRing - 1)][lane] = make_double2(sr[0], si[0]);
+        ++step;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS executes a wave's instructions in order
+        __hip_atomic_store(prod, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    if constexpr (MODE != 0) {
+        // ---- block-unrolled reverse walk: per block  [dg(b+1,0)]^-1 ring^-1 publish RY(b,LD)^-1 ... [dg(b,1)]^-1 publish RX(b)^-1
+        constexpr int LD = MODE, RPB = 1 + LD;
+        const int nb = a.nblocks;
+        wait_vmcnt<0>();                                      // the forward sweep's run-ahead fetches target the same slots
+#pragma unroll
+        for (int i = 0; i <= kBDist; ++i) bs.issue(nb - i);
+        wait_vmcnt<kBDist * RPB>();                           // block nb's slot: its record 0 is the final diagonal
+        double2 dgn = bs.rd(bs.slot(nb), bs.a_dg);
+        bs.template step<-1>(nb);                             // block nb-1 landed
+        bs.load_records(bs.slot(nb - 1));
+        int bl = nb - 1, col = E;
+        bs.load_cs(csrow, col - a.runs.enc[a.runs.nruns - 1], E);
+        for (int ri = a.runs.nruns - 1; ri >= 0; --ri) {
+            const int m = a.runs.enc[ri];
+            for (int rep = 0; rep < a.runs.count[ri]; ++rep) {
+                bs.template step<-1>(bl);                     // block bl-1 landed
+                const char* nx = bs.slot(bl - 1);
+#pragma unroll
+                for (int s = LD - 1; s >= 0; --s) {
+                    if (s == LD - 1) {
+                        apply_phase<true>(sr[0], si[0], dgn);
+                    } else {
+                        apply_phase<true>(sr[0], si[0], bs.dg[s + 2]);
+                        bs.dg[s + 2] = bs.rd(nx, (s + 2) * kRecBytes + bs.a_dg);
+                    }
+                    sr[0] = lane_gather(sr[0], ring_rev);
+                    si[0] = lane_gather(si[0], ring_rev);
+                    publish();
+                    static_rfor<0, N>([&](auto q) {
+                        constexpr int Q = decltype(q)::value;
+                        apply_ry<Q, true>(sr[0], si[0], bs.ry[s][Q]);
+                        bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
+                    });
+                }
+                apply_phase<true>(sr[0], si[0], bs.dg[1]);
+                bs.dg[1] = bs.rd(nx, kRecBytes + bs.a_dg);
+                publish();
+                rfor_gates_below<N>(m, [&](auto q) {
+                    constexpr int Q = decltype(q)::value;
+                    apply_rx<N, Q>(sr, si, bs.cs[Q].x, -bs.cs[Q].y);
+                });
+                dgn = bs.dg[0];
+                bs.dg[0] = bs.rd(nx, bs.a_dg);
+                col -= m;
+                const int m_prev = (rep + 1 < a.runs.count[ri]) ? m : (ri > 0 ? a.runs.enc[ri - 1] : 0);
+                bs.load_cs(csrow, col - m_prev, E);
+                --bl;
             }
-            ring[step & (kPairRing - 1)][lane] = make_double2(sr[0], si[0]);
-            ++step;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS executes a wave's instructions in order
-            __hip_atomic_store(prod, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        // reverse walk over the layers: [diagonal of record l+1]^-1, ring^-1 (ansatz), publish, [layer l]^-1
+        }
+    } else {
+        // ---- generic reverse walk over the layers: [diagonal of record l+1]^-1, ring^-1 (ansatz), publish, [layer l]^-1
         int l = a.L - 1, col = E;
+        wait_vmcnt<0>();                                   // the forward sweep's run-ahead fetches target the same slots
         ls.template prime<-1>(a.L);                        // record L read: dg = final diagonal
         {   // bring record L-1 in and read its coefficients (prime read the RY slots of record L: unused padding)
             ls.template begin<-1>(a.L);
@@ -375,6 +561,43 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_ztri_kernel(ZBwdAr
                 col -= ne;
             }
         }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_ztri_kernel(ZBwdArgs a) {
+    using C = Cfg<N>;
+    static_assert(C::R == 1 && kSigmaWaves == 2, "all-lane layout, two sigma waves");
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // SPW x E (cos, sin)
+    __shared__ __attribute__((aligned(16))) char rec_ring[2 * kBlockRingBytes];
+    __shared__ double2 psi_ring[kPairRing][64];
+    __shared__ double2 lam_ring[kPairRing][64];
+    __shared__ double2 psi_final[64];
+    __shared__ TriSync sync;
+
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0: psi, 1: lambda, 2..: sigma
+    const long wave = blockIdx.x;                                                 // one sample group per workgroup
+    const long b_raw = wave * C::SPW + (lane >> C::LB);
+    const bool valid = b_raw < a.B;
+    const long b = valid ? b_raw : a.B - 1;
+    const int klow = lane & (C::LANES - 1);
+    const int E = a.E;
+
+    if (threadIdx.x == 0) {
+        sync.psi_prod = 0; sync.lam_prod = 0; sync.ready = 0; sync.abort = 0;
+        for (int w = 0; w < kSigmaWaves; ++w) sync.cursor[w] = w;
+    }
+    double2* cs = reinterpret_cast<double2*>(dyn_lds);
+    fill_cs(cs, a.src, E, wave * C::SPW, a.B, C::SPW, (int)threadIdx.x, 128 + 64 * kSigmaWaves);   // all four waves
+    __syncthreads();
+
+    if (role < 2) {
+        // ------------------------------------------------------------------ psi / lambda chains
+        char* my_ring = rec_ring + role * kBlockRingBytes;
+        if (a.fast_ld == 2) ztri_chain<N, 2>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+        else if (a.fast_ld == 1) ztri_chain<N, 1>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+        else ztri_chain<N, 0>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
     } else {
         // ------------------------------------------------------------------ sigma waves: inner products + sums
         double* __restrict__ part_w = a.partial + wave * (long)a.blk * C::KW;

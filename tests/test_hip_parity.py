@@ -139,6 +139,32 @@ def test_random_block_shapes(dev, n, backward_variant):
             np.testing.assert_allclose(gw, rgw, rtol=0, atol=TOL, err_msg=msg)
 
 
+@pytest.mark.parametrize('ld', [1, 2])
+@pytest.mark.parametrize('n', [2, 3, 4, 5])
+def test_uniform_block_shapes(dev, n, ld, backward_variant):
+    """Circuits whose blocks all have one RX chunk (0 < enc <= n) and the same number of sub-layers (what the reference
+    builds: ld = 2 in every script, 1 in the shipped Q2 checkpoint) take the block-unrolled walk of hea_zyz.hpp under
+    'ztri' / 'auto'; runs of different enc, a single block, ragged batches, with and without the saved final state."""
+    rng = np.random.default_rng(4000 + 10 * n + ld)
+    for cfgs, B in [([(n, ld)] * 3 + [(n - 1, ld)] * 2 + [(1, ld)], 2 * max(1, 64 >> n) + 1), ([(n, ld)], 3),
+                    ([(1, ld)] * 2 + [(n, ld)] * 5, 70)]:
+        E, blk = O.circuit_sizes(n, cfgs)
+        x = rng.uniform(-np.pi, np.pi, (B, E))
+        w = rng.uniform(-np.pi, np.pi, (blk, 3, n))
+        g = rng.normal(size=B)
+        off, co = O.ham_params(n, -2.0, 5.0)
+        ro, rst = C.hea_forward(n, cfgs, x, w, off, co, return_state=True)
+        _, rgx, rgw = C.hea_backward(n, cfgs, x, w, g, off, co)
+        for use_state in (True, False):
+            out, st, gx, gw, out2 = _run(n, cfgs, x, w, g, dev, off, co, use_state=use_state)
+            msg = f"n={n} cfgs={cfgs} B={B} use_state={use_state}"
+            np.testing.assert_allclose(out, ro, rtol=0, atol=TOL, err_msg=msg)
+            np.testing.assert_allclose(out2, ro, rtol=0, atol=TOL, err_msg=msg)
+            np.testing.assert_allclose(st, rst, rtol=0, atol=TOL, err_msg=msg)
+            np.testing.assert_allclose(gx, rgx, rtol=0, atol=TOL, err_msg=msg)
+            np.testing.assert_allclose(gw, rgw, rtol=0, atol=TOL, err_msg=msg)
+
+
 def test_ham_diag_readout(dev):
     n, cfgs = 4, [(4, 1), (4, 2)]
     rng = np.random.default_rng(7)
