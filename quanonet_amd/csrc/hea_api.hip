@@ -153,6 +153,12 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
             const int h = ring_src_index(n, j);
             for (int q = 0; q < n; ++q) ph = cmul(ph, ((h >> q) & 1) ? cconj(gz[1][q].u) : gz[1][q].u);
         }
+        // wire 4 of a full RX chunk runs as RZ(-pi/2) RY RZ(pi/2) (hea_zyz.hpp, apply_enc): RZ(pi/2) goes into the
+        // diagonal before the chunk, RZ(-pi/2) into the one after it; RZ(phi)|b> = e^{-i phi/2 (1 - 2b)}|b>
+        constexpr double kR = 0.70710678118654752440;
+        const bool one = (j >> 4) & 1;
+        if (n == 5 && cur.kind == 0 && cur.m == 5) ph = cmul(ph, make_double2(kR, one ? kR : -kR));
+        if (n == 5 && prev.kind == 0 && prev.m == 5) ph = cmul(ph, make_double2(kR, one ? -kR : kR));
         reinterpret_cast<double2*>(out)[j] = ph;
     } else if (j >= 32 && j < 32 + 2 * n) {
         const int q = (j - 32) >> 1, var = (j - 32) & 1;

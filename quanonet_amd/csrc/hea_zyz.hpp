@@ -80,13 +80,40 @@ __device__ __forceinline__ void apply_phase(double& re, double& im, const double
     im = d.x * im + s * re;
     re = nr;
 }
-// RY(theta) = [[c, -s], [s, c]] on lane qubit Q; u = (c, sv) with sv = -s for lane-bit 0 and +s for lane-bit 1
+// RY(theta) = [[c, -s], [s, c]] on lane qubit Q.
+// Q < 4: u = (c, sv) with sv = -s for lane-bit 0 and +s for lane-bit 1 (the lane's variant of the record); the partner
+//        comes through DPP.
+// Q = 4: the partner is 16 lanes away, outside DPP's reach; ds_swizzle would put 52 clocks of LDS latency on the
+//        chain.  v_permlane16_swap_b32 (gfx950) swaps the odd 16-lane rows of one register with the even rows of
+//        another: swapping re with im leaves (re_a, re_b) in the lanes of an even row and (im_a, im_b) in those of
+//        the odd row, a and b being the two partner amplitudes -- every lane then rotates the PAIR it holds with the
+//        SAME (c, s), and a second swap puts the results back: 4 swaps + 4 fp64 operations, all on the vector pipe,
+//        no lane-dependent coefficient.  u = (c, s) for every lane.
 template <int Q, bool DAGGER>
 __device__ __forceinline__ void apply_ry(double& re, double& im, const double2& u) {
-    const double qr = xchg<(1 << Q)>(re), qi = xchg<(1 << Q)>(im);
     const double sv = DAGGER ? -u.y : u.y;
-    re = u.x * re + sv * qr;
-    im = u.x * im + sv * qi;
+    if constexpr (Q == 4) {
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(re), (unsigned)__double2loint(im), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(re), (unsigned)__double2hiint(im), false, false);
+        const double a = __hiloint2double((int)hi[0], (int)lo[0]), b = __hiloint2double((int)hi[1], (int)lo[1]);
+        const double o1 = u.x * a - sv * b, o2 = sv * a + u.x * b;
+        const auto l2 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(o1), (unsigned)__double2loint(o2), false, false);
+        const auto h2 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(o1), (unsigned)__double2hiint(o2), false, false);
+        re = __hiloint2double((int)h2[0], (int)l2[0]);
+        im = __hiloint2double((int)h2[1], (int)l2[1]);
+    } else {
+        const double qr = xchg<(1 << Q)>(re), qi = xchg<(1 << Q)>(im);
+        re = u.x * re + sv * qr;
+        im = u.x * im + sv * qi;
+    }
+}
+// RX(x) of the encoding layers, cs = (cos x/2, sin x/2).  Q < 4: the native gate.  Q = 4: RX = RZ(-pi/2) RY RZ(pi/2), the
+// two fixed phases folded into the diagonals before and after the layer by prep_zyz_kernel, so that this gate too is
+// the swap-form RY above (its gradient is then the Y inner product, not the X one: sigma waves).
+template <int N, int Q, bool DAGGER>
+__device__ __forceinline__ void apply_enc(double (&re)[1], double (&im)[1], const double2& cs) {
+    if constexpr (Q == 4) apply_ry<4, DAGGER>(re[0], im[0], cs);
+    else apply_rx<N, Q>(re, im, cs.x, DAGGER ? -cs.y : cs.y);
 }
 
 // Layer records stream: global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: every lane's 16 bytes land at
@@ -130,7 +157,7 @@ struct LayerStream {
         L = nlayers;
         static_for<0, N>([&](auto q) {
             constexpr int Q = decltype(q)::value;
-            voff[Q] = kRecRy + Q * 32 + (((unsigned)lane >> Q) & 1u) * 16u;
+            voff[Q] = kRecRy + Q * 32 + (Q == 4 ? 1u : (((unsigned)lane >> Q) & 1u)) * 16u;     // Q = 4: (c, +s) for all lanes
         });
     }
     __device__ __forceinline__ void issue(int l) const {           // records outside [0, L] repeat an end record (never read)
@@ -190,7 +217,7 @@ __device__ __forceinline__ void zyz_forward(double (&re)[1], double (&im)[1], co
                 ls.dg = ls.rd_diag(l + 1);
                 for_gates_below<N>(m, [&](auto q) {
                     constexpr int Q = decltype(q)::value;
-                    apply_rx<N, Q>(re, im, nxt[Q].x, nxt[Q].y);
+                    apply_enc<N, Q, false>(re, im, nxt[Q]);
                 });
                 prefetch(col + j0 + m);               // columns are consumed in order: the next chunk starts here
                 ls.rd_all_ry(l + 1);                  // an RX chunk uses none: read the next record's in one go
@@ -216,7 +243,7 @@ __device__ __forceinline__ void zyz_forward(double (&re)[1], double (&im)[1], co
 }
 
 // ---------------------------------------------------------------------------------------
-// Block-unrolled fast path.  Every circuit the reference builds has blocks of ONE RX chunk (0 < enc <= n) followed
+// Block-unrolled fast path.  Every circuit the reference builds has blocks of ONE full RX chunk (enc = n) followed
 // by the same number LD of sub-layers (1 or 2: every script uses 2, the shipped Q2 checkpoint 1).  For those the
 // layer loop is unrolled over a whole block: a block's 1 + LD records are fetched together (kBDist blocks ahead),
 // every coefficient lives in a register of its own that is refilled with the NEXT block's value right after its last
@@ -249,7 +276,7 @@ struct BlockStream {
         a_dg = (unsigned)klow * 16u;
         static_for<0, N>([&](auto q) {
             constexpr int Q = decltype(q)::value;
-            a_ry[Q] = kRecRy + Q * 32 + (((unsigned)lane >> Q) & 1u) * 16u;
+            a_ry[Q] = kRecRy + Q * 32 + (Q == 4 ? 1u : (((unsigned)lane >> Q) & 1u)) * 16u;     // Q = 4: (c, +s) for all lanes
         });
     }
     __device__ __forceinline__ void issue(int b) const {             // b in [-(kBDist+1), nblocks + kBDist + 1]
@@ -285,7 +312,7 @@ __host__ __device__ inline int zyz_fast_ld(const Runs& r, int n) {      // LD of
     const int ld = r.ld[0];
     if (ld != 1 && ld != 2) return 0;
     for (int i = 0; i < r.nruns; ++i)
-        if (r.ld[i] != ld || r.enc[i] < 1 || r.enc[i] > n || r.count[i] < 1) return 0;
+        if (r.ld[i] != ld || r.enc[i] != n || r.count[i] < 1) return 0;
     return ld;
 }
 
@@ -308,9 +335,9 @@ __device__ __forceinline__ void zyz_forward_fast(double (&re)[1], double (&im)[1
             const char* nx = bs.slot(b + 1);
             apply_phase<false>(re[0], im[0], bs.dg[0]);
             bs.dg[0] = bs.rd(nx, bs.a_dg);
-            for_gates_below<N>(m, [&](auto q) {
+            static_for<0, N>([&](auto q) {
                 constexpr int Q = decltype(q)::value;
-                apply_rx<N, Q>(re, im, bs.cs[Q].x, bs.cs[Q].y);
+                apply_enc<N, Q, false>(re, im, bs.cs[Q]);
             });
             col += m;
             bs.load_cs(csrow, col, E);
@@ -492,9 +519,9 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
                 apply_phase<true>(sr[0], si[0], bs.dg[1]);
                 bs.dg[1] = bs.rd(nx, kRecBytes + bs.a_dg);
                 publish();
-                rfor_gates_below<N>(m, [&](auto q) {
+                static_rfor<0, N>([&](auto q) {
                     constexpr int Q = decltype(q)::value;
-                    apply_rx<N, Q>(sr, si, bs.cs[Q].x, -bs.cs[Q].y);
+                    apply_enc<N, Q, true>(sr, si, bs.cs[Q]);
                 });
                 dgn = bs.dg[0];
                 bs.dg[0] = bs.rd(nx, bs.a_dg);
@@ -553,7 +580,7 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
                     ls.template begin<-1>(l);
                     rfor_gates_below<N>(m, [&](auto q) {
                         constexpr int Q = decltype(q)::value;
-                        apply_rx<N, Q>(sr, si, nxt[Q].x, -nxt[Q].y);
+                        apply_enc<N, Q, true>(sr, si, nxt[Q]);
                     });
                     ls.rd_all_ry(l - 1);                    // an RX chunk uses none: read the next record's in one go
                     --l;
@@ -650,7 +677,12 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_ztri_kernel(ZBwdAr
                     for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
                     for_gates_below<N>(m, [&](auto q) {
                         constexpr int Q = decltype(q)::value;
-                        gx[Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
+                        if constexpr (Q == 4) {           // this wire's encoding gate runs as RY (apply_enc): Y inner product
+                            const double sg = ((lane >> Q) & 1) ? -1.0 : 1.0;
+                            gx[Q] = -sg * (lm.x * qv[Q].x + lm.y * qv[Q].y);
+                        } else {
+                            gx[Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
+                        }
                     });
                     store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, col - ne + ch * N, m);
                 }
