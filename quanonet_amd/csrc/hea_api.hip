@@ -403,7 +403,7 @@ int launch_zyz_forward(int n, const Shape& sh, int64_t B, const Layout& L, char*
     const ZFwdArgs za{sh.runs, (long)B, (int)sh.E, ws + L.off_rec, (int)((L.zL + 1) * kRecBytes), L.zL, src, off, co, diag,
                       pauli, out, state_out, bias, fast, nblocks};
     const dim3 grid((unsigned)(L.nwaves_fwd / kWaves));
-    const size_t dyn = (size_t)kWaves * (64 >> n) * sh.E * sizeof(double2);
+    const size_t dyn = (size_t)kWaves * (64 >> n) * zyz_cs_row(n, sh.E) * sizeof(double2);
     switch (n) {
 #define QHEA_CASE(NN) case NN: launch_fwd_zyz_##NN(grid, dyn, st, za); break;
         QHEA_FOR_EACH_ZN(QHEA_CASE)
@@ -421,7 +421,7 @@ int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char
     const ZBwdArgs za{sh.runs, (long)B, (int)sh.E, (int)sh.blk, ws + L.off_rec, (int)((L.zL + 1) * kRecBytes), L.zL, src, off, co,
                       diag, pauli, g, state_in, y, bias, inv_bt, out, grad_x, partial,
                       &reinterpret_cast<WorkspaceHeader*>(ws)->status, fast, nblocks};
-    const size_t dyn = (size_t)(64 >> n) * sh.E * sizeof(double2);
+    const size_t dyn = (size_t)(64 >> n) * zyz_cs_row(n, sh.E) * sizeof(double2);
     switch (n) {
 #define QHEA_CASE(NN) case NN: launch_bwd_ztri_##NN(dim3((unsigned)L.nwaves), dyn, st, za); break;
         QHEA_FOR_EACH_ZN(QHEA_CASE)

@@ -35,8 +35,11 @@ constexpr int kRecBytes = 1024;
 constexpr int kRecRy = 512;
 constexpr int kZCsBytes = 20480;        // LDS bytes of (cos, sin) table per sample group: (64 >> n) * E * 16 must fit
 
+// rows of the (cos, sin) table carry n entries of padding on both sides, so that the run-ahead reads of the
+// block-unrolled walk need no clamping at the ends
+__host__ __device__ inline long zyz_cs_row(int n, long E) { return E + 2 * n; }
 __host__ __device__ inline bool zyz_eligible(int n, long E) {
-    return n >= 2 && n <= 5 && (long)(64 >> n) * E * 16 <= kZCsBytes;
+    return n >= 2 && n <= 5 && (long)(64 >> n) * zyz_cs_row(n, E) * 16 <= kZCsBytes;
 }
 // layers of a block list: per block ceil(enc / n) RX chunks then `ld` sub-layers
 __host__ __device__ inline int zyz_layer_count(const Runs& r, int n) {
@@ -61,13 +64,14 @@ __device__ __forceinline__ double enc_angle(const AngleSrc& a, int E, long b, in
 }
 // rows [s0, s0 + ns) x E of the group's table, spread over `nthreads` threads (tid of them); samples past the batch
 // repeat the last one (their lanes carry lambda = 0)
-__device__ __forceinline__ void fill_cs(double2* cs, const AngleSrc& src, int E, long b0, long B, int ns, int tid, int nthreads) {
+__device__ __forceinline__ void fill_cs(double2* cs, const AngleSrc& src, int n, int E, long b0, long B, int ns, int tid, int nthreads) {
+    const int row = (int)zyz_cs_row(n, E);
     for (int s = 0; s < ns; ++s) {
         const long b = (b0 + s < B) ? b0 + s : B - 1;
         for (int e = tid; e < E; e += nthreads) {
             double sn, cn;
             sincos(0.5 * enc_angle(src, E, b, e), &sn, &cn);
-            cs[s * E + e] = make_double2(cn, sn);
+            cs[s * row + n + e] = make_double2(cn, sn);
         }
     }
 }
@@ -286,9 +290,14 @@ struct BlockStream {
         for (int i = 0; i < RPB; ++i) dma_record(rsrc, slot + i * kRecBytes, lane16, soff + i * kRecBytes);
     }
     __device__ __forceinline__ const char* slot(int b) const { return ring + (b & (kBSlots - 1)) * (RPB * kRecBytes); }
+    // Per block: landed<D>() at the top (blocks b+D .. b+kBDist*D are in flight, b+D must have landed), ahead<D>(b)
+    // later in the block -- in the latency shadow of a ring gather -- fetches block b + (kBDist+1) D.
+    __device__ __forceinline__ void landed() const { wait_vmcnt<(kBDist - 1) * RPB>(); }
     template <int D>
-    __device__ __forceinline__ void step(int b) const {              // block b + D has landed when this returns
-        issue(b + (kBDist + 1) * D);
+    __device__ __forceinline__ void ahead(int b) const { issue(b + (kBDist + 1) * D); }
+    template <int D>
+    __device__ __forceinline__ void step(int b) const {              // both at once (priming)
+        ahead<D>(b);
         wait_vmcnt<kBDist * RPB>();
     }
     static __device__ __forceinline__ double2 rd(const char* p, unsigned off) { return *reinterpret_cast<const double2*>(p + off); }
@@ -299,11 +308,9 @@ struct BlockStream {
         for (int s = 0; s < LD; ++s)
             static_for<0, N>([&](auto q) { ry[s][decltype(q)::value] = rd(sl, (1 + s) * kRecBytes + a_ry[decltype(q)::value]); });
     }
-    __device__ __forceinline__ void load_cs(const double2* __restrict__ csrow, int c0, int E) {
-        static_for<0, N>([&](auto q) {
-            const int e = c0 + decltype(q)::value;
-            cs[decltype(q)::value] = csrow[e < 0 ? 0 : (e < E ? e : E - 1)];
-        });
+    __device__ __forceinline__ void load_cs(const double2* __restrict__ csrow, int c0) {      // c0 in [-N, E]: rows are padded
+        const double2* p = csrow + c0;
+        static_for<0, N>([&](auto q) { cs[decltype(q)::value] = p[decltype(q)::value]; });
     }
 };
 
@@ -326,21 +333,26 @@ __device__ __forceinline__ void zyz_forward_fast(double (&re)[1], double (&im)[1
     for (int i = 0; i <= kBDist; ++i) bs.issue(i);
     wait_vmcnt<kBDist * RPB>();
     bs.load_records(bs.slot(0));
-    bs.load_cs(csrow, 0, E);
+    bs.load_cs(csrow, 0);
     int b = 0, col = 0;
     for (int ri = 0; ri < runs.nruns; ++ri) {
         const int m = runs.enc[ri];
         for (int rep = 0; rep < runs.count[ri]; ++rep) {
-            bs.template step<1>(b);
+            // Every coefficient register is refilled with the next block's value right after its last use, and the
+            // scheduler is kept from sinking those LDS reads towards the ring gather (sched_barrier): queued in
+            // front of the gather they would add their service time to its latency, which the chain waits out.
+            bs.landed();
             const char* nx = bs.slot(b + 1);
             apply_phase<false>(re[0], im[0], bs.dg[0]);
             bs.dg[0] = bs.rd(nx, bs.a_dg);
+            col += m;
+            const double2* cn = csrow + col;
             static_for<0, N>([&](auto q) {
                 constexpr int Q = decltype(q)::value;
                 apply_enc<N, Q, false>(re, im, bs.cs[Q]);
+                bs.cs[Q] = cn[Q];
+                __builtin_amdgcn_sched_barrier(0);
             });
-            col += m;
-            bs.load_cs(csrow, col, E);
 #pragma unroll
             for (int s = 0; s < LD; ++s) {
                 apply_phase<false>(re[0], im[0], bs.dg[1 + s]);
@@ -349,9 +361,12 @@ __device__ __forceinline__ void zyz_forward_fast(double (&re)[1], double (&im)[1
                     constexpr int Q = decltype(q)::value;
                     apply_ry<Q, false>(re[0], im[0], bs.ry[s][Q]);
                     bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
+                    __builtin_amdgcn_sched_barrier(0);
                 });
                 re[0] = lane_gather(re[0], ring_fwd);
                 im[0] = lane_gather(im[0], ring_fwd);
+                if (s == 0) bs.template ahead<1>(b);          // in the gather's shadow
+                __builtin_amdgcn_sched_barrier(0);
             }
             ++b;
         }
@@ -386,9 +401,10 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_zyz_kernel(ZFwdArgs a) {
     const int klow = lane & (C::LANES - 1);
     const int ring_fwd = ring_source<N>(lane, false);
 
-    double2* cs = reinterpret_cast<double2*>(dyn_lds) + (long)wib * C::SPW * a.E;
-    fill_cs(cs, a.src, a.E, wave * C::SPW, a.B, C::SPW, lane, 64);                // wave-private: LDS is in-order per wave
-    const double2* csrow = cs + (lane >> C::LB) * a.E;
+    const int csrow_len = (int)zyz_cs_row(N, a.E);
+    double2* cs = reinterpret_cast<double2*>(dyn_lds) + (long)wib * C::SPW * csrow_len;
+    fill_cs(cs, a.src, N, a.E, wave * C::SPW, a.B, C::SPW, lane, 64);             // wave-private: LDS is in-order per wave
+    const double2* csrow = cs + (lane >> C::LB) * csrow_len + N;
     char* my_ring = rec_ring + wib * kBlockRingBytes;
     double re[1], im[1];
     if (a.fast_ld == 2) {
@@ -429,7 +445,7 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
     const int E = a.E;
     const int ring_fwd = ring_source<N>(lane, false);
     const int ring_rev = ring_source<N>(lane, true);
-    const double2* csrow = cs + (lane >> C::LB) * E;
+    const double2* csrow = cs + (lane >> C::LB) * (int)zyz_cs_row(N, E) + N;
     LayerStream<N> ls;
     BlockStream<N, MODE == 0 ? 1 : MODE> bs;
     if constexpr (MODE == 0) ls.init(a.rec, a.rec_bytes, my_ring, lane, klow, a.L);
@@ -493,11 +509,11 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
         bs.template step<-1>(nb);                             // block nb-1 landed
         bs.load_records(bs.slot(nb - 1));
         int bl = nb - 1, col = E;
-        bs.load_cs(csrow, col - a.runs.enc[a.runs.nruns - 1], E);
+        bs.load_cs(csrow, col - N);
         for (int ri = a.runs.nruns - 1; ri >= 0; --ri) {
             const int m = a.runs.enc[ri];
             for (int rep = 0; rep < a.runs.count[ri]; ++rep) {
-                bs.template step<-1>(bl);                     // block bl-1 landed
+                bs.landed();                                  // block bl-1 landed
                 const char* nx = bs.slot(bl - 1);
 #pragma unroll
                 for (int s = LD - 1; s >= 0; --s) {
@@ -509,25 +525,29 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
                     }
                     sr[0] = lane_gather(sr[0], ring_rev);
                     si[0] = lane_gather(si[0], ring_rev);
+                    if (s == LD - 1) bs.template ahead<-1>(bl);   // in the gather's shadow
+                    __builtin_amdgcn_sched_barrier(0);
                     publish();
                     static_rfor<0, N>([&](auto q) {
                         constexpr int Q = decltype(q)::value;
                         apply_ry<Q, true>(sr[0], si[0], bs.ry[s][Q]);
                         bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
+                        __builtin_amdgcn_sched_barrier(0);
                     });
                 }
                 apply_phase<true>(sr[0], si[0], bs.dg[1]);
                 bs.dg[1] = bs.rd(nx, kRecBytes + bs.a_dg);
                 publish();
+                col -= m;
+                const double2* cn = csrow + (col - N);        // every block has enc = n: the previous block's chunk
                 static_rfor<0, N>([&](auto q) {
                     constexpr int Q = decltype(q)::value;
                     apply_enc<N, Q, true>(sr, si, bs.cs[Q]);
+                    bs.cs[Q] = cn[Q];
+                    __builtin_amdgcn_sched_barrier(0);
                 });
                 dgn = bs.dg[0];
                 bs.dg[0] = bs.rd(nx, bs.a_dg);
-                col -= m;
-                const int m_prev = (rep + 1 < a.runs.count[ri]) ? m : (ri > 0 ? a.runs.enc[ri - 1] : 0);
-                bs.load_cs(csrow, col - m_prev, E);
                 --bl;
             }
         }
@@ -616,7 +636,7 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_ztri_kernel(ZBwdAr
         for (int w = 0; w < kSigmaWaves; ++w) sync.cursor[w] = w;
     }
     double2* cs = reinterpret_cast<double2*>(dyn_lds);
-    fill_cs(cs, a.src, E, wave * C::SPW, a.B, C::SPW, (int)threadIdx.x, 128 + 64 * kSigmaWaves);   // all four waves
+    fill_cs(cs, a.src, N, E, wave * C::SPW, a.B, C::SPW, (int)threadIdx.x, 128 + 64 * kSigmaWaves);   // all four waves
     __syncthreads();
 
     if (role < 2) {
