@@ -71,6 +71,7 @@ __global__ void prep_kernel(int n, int blk, const double* __restrict__ w, double
 struct GateZ {
     double c, s;        // cos(theta/2), sin(theta/2) >= 0
     double2 u, v;       // e^{-i alpha/2}, e^{-i beta/2}
+    double cosb, sinb, cosc, sinc;      // of the FULL angles b = w[s,1,q], c = w[s,2,q] (gradient map of the reduce kernel)
 };
 __device__ __forceinline__ double2 cmul(const double2& a, const double2& b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -97,6 +98,8 @@ __device__ inline GateZ gate_zyz(const double* __restrict__ ws /* w + s*3*n */, 
     else            { u.y = copysign(sqrt(0.5 * (1.0 - z.x)), z.y); u.x = z.y / (2.0 * u.y); }
     g.u = u;
     g.v = cmul(p, cconj(u));
+    g.cosb = cb * cb - sb * sb; g.sinb = 2.0 * sb * cb;
+    g.cosc = cc * cc - sc * sc; g.sinc = 2.0 * sc * cc;
     return g;
 }
 
@@ -132,8 +135,11 @@ __device__ inline LayerInfo decode_layer(const Runs& r, int n, int l) {
 //   e^{i Phi_l(k)} = prod_q [pre-diagonal RZ(beta_q) of layer l, if it is an ansatz sub-layer]
 //                  x prod_q [post-diagonal RZ(alpha_q) of layer l-1, if THAT is an ansatz sub-layer, seen through its ring];
 // threads 32 .. 32+2n write the RY coefficients of an ansatz layer.  Native RX chunks have no diagonals of their own.
+// It also leaves, per ansatz gate, the six numbers the reduce kernel's gradient map needs (cos/sin of b, c and alpha),
+// so that the reduce kernel does not spend five serial sincos per gate on them: gmap[s*n + q] = 8 doubles.
+constexpr int kGmapDoubles = 8;
 __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, const double* __restrict__ w,
-                                                      char* __restrict__ rec, WorkspaceHeader* hdr) {
+                                                      char* __restrict__ rec, double* __restrict__ gmap, WorkspaceHeader* hdr) {
     const int l = blockIdx.x, j = threadIdx.x;
     if (l == 0 && j == 0) header_init(hdr);
     const LayerInfo cur = decode_layer(runs, n, l < L ? l : -1), prev = decode_layer(runs, n, l - 1);
@@ -141,7 +147,15 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
     if (j < 2 * n) {                                   // one decomposition per thread, then everybody multiplies phasors
         const int which = j / n, q = j % n;
         const LayerInfo& li = which ? prev : cur;
-        if (li.kind == 1) gz[which][q] = gate_zyz(w + (long)li.s * 3 * n, n, q);
+        if (li.kind == 1) {
+            const GateZ g = gate_zyz(w + (long)li.s * 3 * n, n, q);
+            gz[which][q] = g;
+            if (which == 0) {
+                const double2 z = cmul(g.u, g.u);                    // e^{-i alpha}
+                double* gm = gmap + ((long)li.s * n + q) * kGmapDoubles;
+                gm[0] = g.cosb; gm[1] = g.sinb; gm[2] = g.cosc; gm[3] = g.sinc; gm[4] = z.x; gm[5] = -z.y;
+            }
+        }
     }
     __syncthreads();
     char* out = rec + (long)l * kRecBytes;
@@ -210,16 +224,27 @@ __device__ __forceinline__ void adam_update(const AdamArgs& a, long i, double gi
 __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw, long nwaves,
                                                  const double* __restrict__ partial, const double* w /* may alias adam->p */,
                                                  double* __restrict__ grad_w, double* acc /*[kRedThreads]*/,
-                                                 bool poisoned, bool zyz, const AdamArgs* adam = nullptr, long adam_base = 0) {
+                                                 bool poisoned, const double* __restrict__ gmap /* ZYZ-form sums, or nullptr */,
+                                                 const AdamArgs* adam = nullptr, long adam_base = 0) {
     const int cols = red_cols(kw), nslices = kRedThreads / cols;
     const int j = threadIdx.x % cols, slice = threadIdx.x / cols;
     const long ncols = (long)blk * kw;
     const long v = (long)bid * cols + j;
     acc[slice * cols + j] = v < ncols ? slice_sum(partial + v, nwaves, ncols, slice, nslices) : 0.0;
     __syncthreads();
+    // slices are combined in two fixed-order stages (8 interleaved groups, then those 8): a quarter of the serial
+    // LDS read chain of a single 64-term loop, and still the same order on every run
+    constexpr int kStage = 8;
+    double t8 = 0.0;
+    if (slice < kStage)
+        for (int i = slice; i < nslices; i += kStage) t8 += acc[i * cols + j];
+    __syncthreads();
+    if (slice < kStage) acc[slice * cols + j] = t8;
+    __syncthreads();
     if (slice == 0) {
         double t = 0.0;
-        for (int i = 0; i < nslices; ++i) t += acc[i * cols + j];
+        const int m = nslices < kStage ? nslices : kStage;
+        for (int i = 0; i < m; ++i) t += acc[i * cols + j];
         acc[j] = t;
     }
     __syncthreads();
@@ -230,17 +255,18 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
             double X = acc[j], Y = acc[j + 1];
             const double Z = acc[j + 2];
             const double* ws = w + (long)s * 3 * n;
-            if (zyz) {      // sums taken after the RY layer, before D_post = RZ(alpha): rotate (X, Y) by alpha (hea_zyz.hpp)
-                const GateZ gz = gate_zyz(ws, n, q);
-                const double2 z = cmul(gz.u, gz.u);                  // e^{-i alpha}
-                const double ca = z.x, sa = -z.y;
+            double sb, cb, sc, cc;
+            if (gmap) {     // sums taken after the RY layer, before D_post = RZ(alpha): rotate (X, Y) by alpha (hea_zyz.hpp)
+                const double* gm = gmap + ((long)s * n + q) * kGmapDoubles;
+                cb = gm[0]; sb = gm[1]; cc = gm[2]; sc = gm[3];
+                const double ca = gm[4], sa = gm[5];
                 const double Xr = ca * X - sa * Y;
                 Y = ca * Y + sa * X;
                 X = Xr;
+            } else {
+                sincos(ws[n + q], &sb, &cb);
+                sincos(ws[2 * n + q], &sc, &cc);
             }
-            double sb, cb, sc, cc;
-            sincos(ws[n + q], &sb, &cb);
-            sincos(ws[2 * n + q], &sc, &cc);
             double* gs = grad_w + (long)s * 3 * n;
             double gc = Y, gb = cc * Z + sc * X, ga = cb * Y - sb * cc * X + sb * sc * Z;
             if (poisoned) gc = gb = ga = std::numeric_limits<double>::quiet_NaN();   // the circuit kernel reported an overrun
@@ -261,9 +287,10 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(int n, int blk, int
                                                              const double* __restrict__ partial,
                                                              const double* __restrict__ w,
                                                              double* __restrict__ grad_w,
-                                                             const WorkspaceHeader* __restrict__ hdr, int zyz) {
+                                                             const WorkspaceHeader* __restrict__ hdr,
+                                                             const double* __restrict__ gmap) {
     __shared__ double acc[kRedThreads];
-    reduce_xyz_block(blockIdx.x, n, blk, kw, nwaves, partial, w, grad_w, acc, hdr->status != 0, zyz != 0);
+    reduce_xyz_block(blockIdx.x, n, blk, kw, nwaves, partial, w, grad_w, acc, hdr->status != 0, gmap);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -298,7 +325,7 @@ int make_shape(int n, int nb, const int32_t* enc, const int32_t* ld, Shape& sh) 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t off_U, off_cs, off_part, off_rec, total;
+    size_t off_U, off_cs, off_part, off_rec, off_gmap, total;
     long nwaves, nwaves_fwd;
     bool lds_fwd, lds_bwd, pair;
     bool zfwd, ztri;        // ZYZ-form kernels of hea_zyz.hpp (n <= 5): forward / pipelined backward
@@ -374,6 +401,7 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     L.off_part = p; p = align_up(p + (size_t)L.nwaves * sh.blk * padded_3n(n) * sizeof(double));
     L.off_rec = p;  p = align_up(p + (zok ? (size_t)(L.zL + 1 + 2 * kPadRecs) * kRecBytes : 0));   // padded both sides
     if (zok) L.off_rec += (size_t)kPadRecs * kRecBytes;                                           // -> record 0
+    L.off_gmap = p; p = align_up(p + (zok ? (size_t)sh.blk * n * kGmapDoubles * sizeof(double) : 0));
     L.total = p;
     return L;
 }
@@ -392,7 +420,7 @@ inline void profile_end(hipStream_t st) {
 
 int launch_prep_zyz(int n, const Shape& sh, const double* w, char* ws, const Layout& L, hipStream_t st) {
     hipLaunchKernelGGL(prep_zyz_kernel, dim3((unsigned)(L.zL + 1)), dim3(64), 0, st, sh.runs, n, L.zL, w,
-                       ws + L.off_rec, reinterpret_cast<WorkspaceHeader*>(ws));
+                       ws + L.off_rec, reinterpret_cast<double*>(ws + L.off_gmap), reinterpret_cast<WorkspaceHeader*>(ws));
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 int launch_zyz_forward(int n, const Shape& sh, int64_t B, const Layout& L, char* ws, const AngleSrc& src, double off, double co,
@@ -497,7 +525,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         int n, int blk, int kw, long nwaves, const double* __restrict__ partial, const double* w,
         long B, int E, EncDesc enc, const double* __restrict__ grad_x, const double* __restrict__ pred,
         const double* __restrict__ y, double inv_bt, GradMap gm, int nb_w, int nb_x, double* __restrict__ grad,
-        AdamArgs adam, const WorkspaceHeader* __restrict__ hdr, int zyz) {
+        AdamArgs adam, const WorkspaceHeader* __restrict__ hdr, const double* __restrict__ gmap) {
     __shared__ double acc[kRedThreads];
     __shared__ double acc2[kRedThreads];
     const int bid = blockIdx.x;
@@ -505,7 +533,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
     const double kNaN = std::numeric_limits<double>::quiet_NaN();
     if (poisoned) adam.p = nullptr;
     if (bid < nb_w) {
-        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, poisoned, zyz != 0, &adam, gm.off_ans);
+        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, poisoned, gmap, &adam, gm.off_ans);
     } else if (bid < nb_w + nb_x) {
         const int j = threadIdx.x % kFreqCols, slice = threadIdx.x / kFreqCols;
         const int e = (bid - nb_w) * kFreqCols + j;
@@ -518,15 +546,15 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
             const double* __restrict__ in = sg.in + ee % sg.width;
             const double* __restrict__ gx = grad_x + e;
             long b = slice;
-            for (; b + 3L * kFreqSlices < B; b += 4L * kFreqSlices) {
-                double g[4], v[4];
+            for (; b + 7L * kFreqSlices < B; b += 8L * kFreqSlices) {      // 16 loads in flight per thread
+                double g[8], v[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 8; ++i) {
                     g[i] = gx[(b + (long)i * kFreqSlices) * E];
                     v[i] = in[(b + (long)i * kFreqSlices) * sg.width];
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { s0 += g[i]; s1 += g[i] * v[i]; }
+                for (int i = 0; i < 8; ++i) { s0 += g[i]; s1 += g[i] * v[i]; }
             }
             for (; b < B; b += kFreqSlices) {
                 const double g = gx[b * E];
@@ -813,7 +841,7 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
             const long ncols = sh.blk * kw;
             hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((ncols + red_cols(kw) - 1) / red_cols(kw))), dim3(kRedThreads), 0, st,
                                n_qubits, (int)sh.blk, kw, L.nwaves, partial, w, grad_w,
-                               reinterpret_cast<const WorkspaceHeader*>(ws), 1);
+                               reinterpret_cast<const WorkspaceHeader*>(ws), reinterpret_cast<const double*>(ws + L.off_gmap));
         }
         return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
     }
@@ -841,7 +869,7 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
         const long ncols = sh.blk * padded_3n(n_qubits);
         hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((ncols + red_cols(padded_3n(n_qubits)) - 1) / red_cols(padded_3n(n_qubits)))), dim3(kRedThreads), 0, st,
                            n_qubits, (int)sh.blk, padded_3n(n_qubits), L.nwaves, partial, w, grad_w,
-                           reinterpret_cast<const WorkspaceHeader*>(ws), 0);
+                           reinterpret_cast<const WorkspaceHeader*>(ws), static_cast<const double*>(nullptr));
     }
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
@@ -939,7 +967,8 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
         if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
         hipLaunchKernelGGL(reduce_model_kernel, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
                            (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
-                           gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws), 1);
+                           gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws),
+                           reinterpret_cast<const double*>(ws + M.L.off_gmap));
         return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
     }
     rc = launch_prep_model(mi, batch, params, enc, ws, M.L, st);
@@ -964,7 +993,8 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
     if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
     hipLaunchKernelGGL(reduce_model_kernel, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
                        (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
-                       gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws), 0);
+                       gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws),
+                       static_cast<const double*>(nullptr));
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 

@@ -151,6 +151,29 @@ __device__ __forceinline__ double lane_gather(double v, int src_lane_x4) {
     return __hiloint2double(hi, lo);
 }
 
+// own + partner(lane ^ MASK), the same value in both lanes of the pair.  For the two lane bits DPP cannot reach,
+// gfx950's v_permlane16_swap / v_permlane32_swap applied to (x, copy of x) leave one register holding the own value
+// and the other the partner's in EVERY lane (which is which differs by lane; a sum does not care): 4 vector
+// instructions + the add and no LDS round trip, where ds_swizzle / ds_bpermute put 52 / 60 clocks of latency in
+// front of the add.
+template <int MASK>
+__device__ __forceinline__ double pair_sum(double x) {
+    if constexpr (MASK == 16 || MASK == 32) {
+        const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+        if constexpr (MASK == 16) {
+            const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+            const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+            return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+        } else {
+            const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+            const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+            return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+        }
+    } else {
+        return x + xchg<MASK>(x);
+    }
+}
+
 // Transposing butterfly: K values per lane summed over lane bits [0, BITS).  On return the
 // lane whose low bits are j (j < min(K, 2^BITS)) holds in v[i] the total of value (i << BITS) | j.
 template <int K, int BITS, int T = 0>
@@ -166,7 +189,7 @@ __device__ __forceinline__ void lane_reduce(double (&v)[K], int lane) {
                 v[i] = keep + xchg<(1 << T)>(send);
             }
         } else {
-            v[0] += xchg<(1 << T)>(v[0]);
+            v[0] = pair_sum<(1 << T)>(v[0]);
         }
         lane_reduce<K, BITS, T + 1>(v, lane);
     }

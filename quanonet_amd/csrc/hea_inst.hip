@@ -49,7 +49,7 @@ void QHEA_CAT(launch_fwd_zyz_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st
     hipLaunchKernelGGL(fwd_zyz_kernel<QHEA_N>, grid, dim3(kWaves * 64), dyn_lds, st, a);
 }
 void QHEA_CAT(launch_bwd_ztri_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a) {
-    hipLaunchKernelGGL(bwd_ztri_kernel<QHEA_N>, grid, dim3(128 + 64 * kSigmaWaves), dyn_lds, st, a);
+    hipLaunchKernelGGL(bwd_ztri_kernel<QHEA_N>, grid, dim3(128 + 64 * kZSigma), dyn_lds, st, a);
 }
 #elif QHEA_N <= 5      // layout-experiment build: the ZYZ kernels need the all-lane layout and are never selected
 void QHEA_CAT(launch_fwd_zyz_, QHEA_N)(dim3, size_t, hipStream_t, const ZFwdArgs&) {}

@@ -138,6 +138,11 @@ template <int CNT>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CNT) : "memory"); }
 
 constexpr int kSlots = 8, kDist = 6;
+#ifndef QHEA_ZSIGMA
+#define QHEA_ZSIGMA 2
+#endif
+constexpr int kZSigma = QHEA_ZSIGMA;            // sigma waves per workgroup of bwd_ztri_kernel: step t belongs to wave t % kZSigma
+struct ZSync { int psi_prod, lam_prod, ready, abort; int cursor[kZSigma]; };
 constexpr int kRecRingBytes = kSlots * kRecBytes;           // per streaming wave
 
 template <int N>
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_zyz_kernel(ZFwdArgs a) {
 template <int N, int MODE>
 __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane, int klow, bool valid, long b,
                                            const double2* cs, char* my_ring, double2 (*psi_ring)[64],
-                                           double2 (*lam_ring)[64], double2* psi_final, TriSync* sync) {
+                                           double2 (*lam_ring)[64], double2* psi_final, ZSync* sync) {
     using C = Cfg<N>;
     __builtin_amdgcn_s_setprio(3);                          // the chains are the critical path (hea_device.hpp)
     const int E = a.E;
@@ -451,9 +456,9 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
     if constexpr (MODE == 0) ls.init(a.rec, a.rec_bytes, my_ring, lane, klow, a.L);
     else bs.init(a.rec, a.L + 1, my_ring, lane, klow);
     double sr[1], si[1];
-    int seen[kSigmaWaves];
+    int seen[kZSigma];
 #pragma unroll
-    for (int w = 0; w < kSigmaWaves; ++w) seen[w] = 0;
+    for (int w = 0; w < kZSigma; ++w) seen[w] = 0;
     if (role == 0) {
         if (a.state_in) {
             const double2 s0 = reinterpret_cast<const double2*>(a.state_in)[(b << N) + klow];
@@ -488,7 +493,7 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
     auto publish = [&]() {
         if (step >= kPairRing) {
 #pragma unroll
-            for (int w = 0; w < kSigmaWaves; ++w)
+            for (int w = 0; w < kZSigma; ++w)
                 pair_wait_ge(&sync->cursor[w], step - kPairRing + 1, &sync->abort, seen[w]);
         }
         ring[step & (kPairRing - 1)][lane] = make_double2(sr[0], si[0]);
@@ -498,14 +503,14 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
     };
 
     if constexpr (MODE != 0) {
-        // ---- block-unrolled reverse walk: per block  [dg(b+1,0)]^-1 ring^-1 publish RY(b,LD)^-1 ... [dg(b,1)]^-1 publish RX(b)^-1
+        // ---- block-unrolled reverse walk: per block  ring^-1 publish RY(b,LD)^-1 [dg(b,LD)]^-1 ... [dg(b,1)]^-1 publish RX(b)^-1 [dg(b,0)]^-1
         constexpr int LD = MODE, RPB = 1 + LD;
         const int nb = a.nblocks;
         wait_vmcnt<0>();                                      // the forward sweep's run-ahead fetches target the same slots
 #pragma unroll
         for (int i = 0; i <= kBDist; ++i) bs.issue(nb - i);
         wait_vmcnt<kBDist * RPB>();                           // block nb's slot: its record 0 is the final diagonal
-        double2 dgn = bs.rd(bs.slot(nb), bs.a_dg);
+        apply_phase<true>(sr[0], si[0], bs.rd(bs.slot(nb), bs.a_dg));
         bs.template step<-1>(nb);                             // block nb-1 landed
         bs.load_records(bs.slot(nb - 1));
         int bl = nb - 1, col = E;
@@ -517,10 +522,8 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
                 const char* nx = bs.slot(bl - 1);
 #pragma unroll
                 for (int s = LD - 1; s >= 0; --s) {
-                    if (s == LD - 1) {
-                        apply_phase<true>(sr[0], si[0], dgn);
-                    } else {
-                        apply_phase<true>(sr[0], si[0], bs.dg[s + 2]);
+                    if (s != LD - 1) {                        // (the diagonal after the block's last sub-layer was undone
+                        apply_phase<true>(sr[0], si[0], bs.dg[s + 2]);     //  at the end of the previous iteration)
                         bs.dg[s + 2] = bs.rd(nx, (s + 2) * kRecBytes + bs.a_dg);
                     }
                     sr[0] = lane_gather(sr[0], ring_rev);
@@ -546,8 +549,8 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
                     bs.cs[Q] = cn[Q];
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                dgn = bs.dg[0];
-                bs.dg[0] = bs.rd(nx, bs.a_dg);
+                apply_phase<true>(sr[0], si[0], bs.dg[0]);    // the diagonal in front of this block's RX chunk: every
+                bs.dg[0] = bs.rd(nx, bs.a_dg);                // diagonal an iteration undoes is one of its own records
                 --bl;
             }
         }
@@ -612,15 +615,15 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
 }
 
 template <int N>
-__global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_ztri_kernel(ZBwdArgs a) {
+__global__ __launch_bounds__(128 + 64 * kZSigma) void bwd_ztri_kernel(ZBwdArgs a) {
     using C = Cfg<N>;
-    static_assert(C::R == 1 && kSigmaWaves == 2, "all-lane layout, two sigma waves");
+    static_assert(C::R == 1, "all-lane layout");
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // SPW x E (cos, sin)
     __shared__ __attribute__((aligned(16))) char rec_ring[2 * kBlockRingBytes];
     __shared__ double2 psi_ring[kPairRing][64];
     __shared__ double2 lam_ring[kPairRing][64];
     __shared__ double2 psi_final[64];
-    __shared__ TriSync sync;
+    __shared__ ZSync sync;
 
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0: psi, 1: lambda, 2..: sigma
@@ -633,10 +636,10 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_ztri_kernel(ZBwdAr
 
     if (threadIdx.x == 0) {
         sync.psi_prod = 0; sync.lam_prod = 0; sync.ready = 0; sync.abort = 0;
-        for (int w = 0; w < kSigmaWaves; ++w) sync.cursor[w] = w;
+        for (int w = 0; w < kZSigma; ++w) sync.cursor[w] = w;
     }
     double2* cs = reinterpret_cast<double2*>(dyn_lds);
-    fill_cs(cs, a.src, N, E, wave * C::SPW, a.B, C::SPW, (int)threadIdx.x, 128 + 64 * kSigmaWaves);   // all four waves
+    fill_cs(cs, a.src, N, E, wave * C::SPW, a.B, C::SPW, (int)threadIdx.x, 128 + 64 * kZSigma);   // all waves
     __syncthreads();
 
     if (role < 2) {
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_ztri_kernel(ZBwdAr
             for (int rep = 0; rep < a.runs.count[ri]; ++rep) {
                 for (int s = nld - 1; s >= 0; --s) {
                     --sub;
-                    if ((step & 1) != me) { ++step; continue; }
+                    if (step % kZSigma != me) { ++step; continue; }
                     pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
                     pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
                     const double2* slot = psi_ring[step & (kPairRing - 1)];
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_ztri_kernel(ZBwdAr
                     double2 qv[N];
                     static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
                     const double2 lm = lam_ring[step & (kPairRing - 1)][lane];
-                    __hip_atomic_store(&sync.cursor[me], step + kSigmaWaves, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&sync.cursor[me], step + kZSigma, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ++step;
                     double acc3[C::KW];
 #pragma unroll
@@ -683,14 +686,14 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_ztri_kernel(ZBwdAr
                 }
                 for (int ch = nch - 1; ch >= 0; --ch) {
                     const int m = ch == nch - 1 ? m_last : N;
-                    if ((step & 1) != me) { ++step; continue; }
+                    if (step % kZSigma != me) { ++step; continue; }
                     pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
                     pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
                     const double2* slot = psi_ring[step & (kPairRing - 1)];
                     double2 qv[N];
                     static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
                     const double2 lm = lam_ring[step & (kPairRing - 1)][lane];
-                    __hip_atomic_store(&sync.cursor[me], step + kSigmaWaves, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&sync.cursor[me], step + kZSigma, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ++step;
                     double gx[C::KX];
 #pragma unroll
