@@ -392,7 +392,14 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     // variants stay selectable (qhea_set_backward_variant) and take over for shapes whose (cos, sin) table exceeds LDS
     const int var = g_bwd_variant.load(std::memory_order_relaxed);
     const bool zok = zyz_eligible(n, sh.E) && n != QHEA_EXP_N && (var == QHEA_BWD_AUTO || var == QHEA_BWD_ZTRI);
-    L.zfwd = zok;
+    // Measured at cfg 2's circuit (us per call incl. prep / reduce; first-generation / ZYZ form):
+    //   forward   B = 1024 58 / 47,  4096 95 / 96,  16384 266 / 290: the ZYZ forward keeps 22 KB of LDS per wave (whole
+    //             (cos, sin) table + record ring), which caps the waves per CU once the batch could fill them
+    //   backward  B = 1024 packed 186, tri 134, ztri 115;  2048 257 / 261 / 221;  4096 319 / 408 / 421
+    // so AUTO takes the ZYZ forward up to two waves per SIMD and the ZYZ pipeline up to one sample group per SIMD.
+    if (var == QHEA_BWD_AUTO && zok && !L.lds_bwd && n <= 5 && B > 0) L.pair = L.nwaves_fwd <= (long)simd_count();
+    if (L.pair) L.nwaves = (B + spw - 1) / spw;
+    L.zfwd = zok && (var == QHEA_BWD_ZTRI || L.nwaves_fwd <= 2L * simd_count());
     L.ztri = zok && L.pair;
     L.zL = zok ? zyz_layer_count(sh.runs, n) : 0;
     size_t p = kHeaderBytes;                         // WorkspaceHeader

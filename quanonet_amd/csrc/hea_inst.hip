@@ -46,7 +46,7 @@ void QHEA_CAT(launch_bwd_pair_, QHEA_N)(dim3 grid, hipStream_t st, const BwdArgs
 
 #if QHEA_N <= 5 && QHEA_N != QHEA_EXP_N
 void QHEA_CAT(launch_fwd_zyz_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArgs& a) {
-    hipLaunchKernelGGL(fwd_zyz_kernel<QHEA_N>, grid, dim3(kWaves * 64), dyn_lds, st, a);
+    hipLaunchKernelGGL(fwd_zyz_kernel<QHEA_N>, grid, dim3((kWaves + kFwdHelpers) * 64), dyn_lds, st, a);
 }
 void QHEA_CAT(launch_bwd_ztri_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a) {
     hipLaunchKernelGGL(bwd_ztri_kernel<QHEA_N>, grid, dim3(128 + 64 * kZSigma), dyn_lds, st, a);

@@ -391,14 +391,25 @@ struct ZBwdArgs {
     int fast_ld, nblocks;
 };
 
+// kWaves sweeping waves + kFwdHelpers waves that only help to fill the (cos, sin) tables and then leave: the fill is
+// 2 x 600 fp64 sincos at cfg 2, ~4 us if each sweeping wave does its own, and the sweep cannot start before it.
+constexpr int kFwdHelpers = 2;
 template <int N>
-__global__ __launch_bounds__(kWaves * 64) void fwd_zyz_kernel(ZFwdArgs a) {
+__global__ __launch_bounds__((kWaves + kFwdHelpers) * 64) void fwd_zyz_kernel(ZFwdArgs a) {
     using C = Cfg<N>;
     static_assert(C::R == 1, "all-lane layout");
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // kWaves x SPW x E (cos, sin)
     __shared__ __attribute__((aligned(16))) char rec_ring[kWaves * kBlockRingBytes];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    {
+        const int csrow_len = (int)zyz_cs_row(N, a.E);
+        fill_cs(reinterpret_cast<double2*>(dyn_lds), a.src, N, a.E, (long)blockIdx.x * kWaves * C::SPW, a.B, kWaves * C::SPW,
+                (int)threadIdx.x, (kWaves + kFwdHelpers) * 64);
+        (void)csrow_len;
+    }
+    __syncthreads();
+    if (wib >= kWaves) return;
     const long wave = (long)blockIdx.x * kWaves + wib;
     const long b_raw = wave * C::SPW + (lane >> C::LB);
     const bool valid = b_raw < a.B;
@@ -408,7 +419,6 @@ __global__ __launch_bounds__(kWaves * 64) void fwd_zyz_kernel(ZFwdArgs a) {
 
     const int csrow_len = (int)zyz_cs_row(N, a.E);
     double2* cs = reinterpret_cast<double2*>(dyn_lds) + (long)wib * C::SPW * csrow_len;
-    fill_cs(cs, a.src, N, a.E, wave * C::SPW, a.B, C::SPW, lane, 64);             // wave-private: LDS is in-order per wave
     const double2* csrow = cs + (lane >> C::LB) * csrow_len + N;
     char* my_ring = rec_ring + wib * kBlockRingBytes;
     double re[1], im[1];

@@ -284,3 +284,26 @@ def test_model_level_oracle_equals_torch_autograd_through_the_product_modules(ki
     assert {k for k, _ in m.named_parameters()} == set(rg)
     for k, prm in m.named_parameters():
         np.testing.assert_allclose(prm.grad.numpy().reshape(-1), rg[k].reshape(-1), rtol=0, atol=1e-12, err_msg=k)
+
+
+def _demo_rows():
+    d = np.load(H.GOLDEN + '/antideriv_demo.npz')
+    branch = np.repeat(d['u0'].astype(np.float64), 100, axis=0)
+    trunk = np.tile(d['x'].astype(np.float64), 1000)[:, None]
+    return branch, trunk, d['u'].astype(np.float64).reshape(-1)
+
+
+def test_k9_readme_demo_figures():
+    """README.md:137-155: `python infer.py --ckpt .../Antideriv_..._Q2.../best_model.npz` prints Rel-L2 0.1192, MSE 0.002609,
+    MAE 0.037747 on a freshly generated test set (RNG dependent: "same order of magnitude").  On the set drawn under
+    np.random.seed(0) (tests/golden/make_golden.py k9) the oracle gives 0.1195 / 0.002478 / 0.037077."""
+    ka = H.known_answers()['K9']
+    p = H.load_pt_params('antideriv_q2.npz', 2, (5, 1, 5, 1))
+    branch, trunk, y = _demo_rows()
+    out = O.quanonet_forward(p, branch, trunk, 2, (5, 1, 5, 1), engine=C)
+    diff = out - y
+    rel = np.linalg.norm(diff) / np.linalg.norm(y)
+    assert abs(rel - ka['seed0']['rel_l2']) < 5e-4 and abs(np.mean(diff ** 2) - ka['seed0']['mse']) < 5e-6
+    assert abs(np.mean(np.abs(diff)) - ka['seed0']['mae']) < 5e-5
+    for k, v in (('rel_l2', rel), ('mse', np.mean(diff ** 2)), ('mae', np.mean(np.abs(diff)))):
+        assert abs(v - ka['readme'][k]) < 0.1 * ka['readme'][k], k        # within 10 % of the README's own sample

@@ -260,3 +260,26 @@ def test_known_answers_k1_k2_on_gpu(dev):
         assert rel < ka[key]['rel_l2_max'], key
         assert abs(rel - ka[key]['survey_rel_l2']) < 2e-3, key
         np.testing.assert_allclose(out, O.quanonet_forward(p, branch, trunk, 2, (5, 1, 5, 1)), rtol=0, atol=TOL)
+
+
+def test_readme_demo_k9_on_gpu(dev):
+    """README.md:137-155 on the HIP path: 100 000 forward evaluations of the shipped Q2 checkpoint (PTSolver.predict's
+    batched qhea_model_forward) on the demo's test set; figures as in tests/test_oracle_golden.py::test_k9..."""
+    from quanonet_amd.models import QuanONetPT
+    from quanonet_amd.solver import regression_metrics
+    ka = H.known_answers()['K9']
+    p = H.load_pt_params('antideriv_q2.npz', 2, (5, 1, 5, 1))
+    model = QuanONetPT(2, 10, 1, (5, 1, 5, 1), scale_coeff=0.001, if_trainable_freq=True)
+    model.load_state_dict({k: torch.tensor(v) for k, v in p.items()})
+    model = model.to(dev).eval()
+    d = np.load(H.GOLDEN + '/antideriv_demo.npz')
+    branch = np.repeat(d['u0'].astype(np.float64), 100, axis=0)
+    trunk = np.tile(d['x'].astype(np.float64), 1000)[:, None]
+    y = d['u'].astype(np.float64).reshape(-1, 1)
+    with torch.no_grad():
+        outs = [model(_t(branch[s:s + 20000], dev), _t(trunk[s:s + 20000], dev)) for s in range(0, 100000, 20000)]
+    pred = torch.cat(outs, dim=0)
+    m = regression_metrics(pred, _t(y, dev))
+    assert abs(m['rel_l2'] - ka['seed0']['rel_l2']) < 5e-4 and abs(m['MSE'] - ka['seed0']['mse']) < 5e-6
+    assert abs(m['MAE'] - ka['seed0']['mae']) < 5e-5
+    assert abs(m['rel_l2'] - ka['readme']['rel_l2']) < 0.1 * ka['readme']['rel_l2']
