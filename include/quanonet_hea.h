@@ -82,7 +82,9 @@ int qhea_device_count(void);
 #define QHEA_BWD_TRI    3      /* psi wave + lambda wave + two inner-product (sigma) waves                            */
 #define QHEA_BWD_ZTRI   4      /* the same pipeline on the ZYZ form of the gates with in-kernel (cos, sin) tables     */
                                /* (what AUTO runs for eligible shapes; the values 1-3 also select the first-          */
-                               /* generation forward kernel, AUTO and ZTRI the ZYZ-form one)                          */
+                               /* generation forward kernel, AUTO, ZTRI and ZPACKED the ZYZ-form one)                 */
+#define QHEA_BWD_ZPACKED 5     /* one wave per sample group in the ZYZ form (what AUTO runs once the batch fills the  */
+                               /* SIMDs, for circuits whose blocks are one full RX chunk + 1 or 2 sub-layers)         */
 int qhea_set_backward_variant(int variant);
 
 /*

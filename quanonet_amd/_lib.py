@@ -29,7 +29,7 @@ class ModelDesc(ctypes.Structure):
 
 MODEL_QUANONET, MODEL_HEAQNN = 0, 1
 MIN_LIB_VERSION = 400           # 0.4.0: workspace header + qhea_check_status / qhea_set_backward_variant
-BWD_VARIANTS = {'auto': 0, 'packed': 1, 'pair': 2, 'tri': 3, 'ztri': 4}
+BWD_VARIANTS = {'auto': 0, 'packed': 1, 'pair': 2, 'tri': 3, 'ztri': 4, 'zpacked': 5}
 PAULI = {'Z': 0, 'X': 1, 'Y': 2}
 
 

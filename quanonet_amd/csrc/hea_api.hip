@@ -328,7 +328,8 @@ struct Layout {
     size_t off_U, off_cs, off_part, off_rec, off_gmap, total;
     long nwaves, nwaves_fwd;
     bool lds_fwd, lds_bwd, pair;
-    bool zfwd, ztri;        // ZYZ-form kernels of hea_zyz.hpp (n <= 5): forward / pipelined backward
+    bool zfwd, zfwd_shared, ztri, zpacked;   // ZYZ-form kernels of hea_zyz.hpp (n <= 5): forward (private / shared record ring),
+                                             // pipelined backward, one-wave backward
     int zL;                 // their layer count (records 0 .. zL)
 };
 
@@ -360,7 +361,7 @@ int use_tri() {                                   // which pipelined variant whe
 bool use_pair(int n, int64_t B) {
     if (n > 5 || B <= 0 || n == QHEA_EXP_N) return false;
     const int v = g_bwd_variant.load(std::memory_order_relaxed);
-    if (v == QHEA_BWD_PACKED) return false;
+    if (v == QHEA_BWD_PACKED || v == QHEA_BWD_ZPACKED) return false;
     if (v == QHEA_BWD_PAIR || v == QHEA_BWD_TRI || v == QHEA_BWD_ZTRI) return true;
     // measured at n = 5 (us per backward call incl. prep/reduce; packed / pipelined): B = 1024 194 / 155, B = 1536
     // 247 / 181, B = 2048 260 / 273 -- pipelined while the sample groups fill at most 3/4 of the SIMDs
@@ -391,16 +392,29 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     // second-generation kernels for n <= 5 (hea_zyz.hpp): the default when the shape is eligible; the first-generation
     // variants stay selectable (qhea_set_backward_variant) and take over for shapes whose (cos, sin) table exceeds LDS
     const int var = g_bwd_variant.load(std::memory_order_relaxed);
-    const bool zok = zyz_eligible(n, sh.E) && n != QHEA_EXP_N && (var == QHEA_BWD_AUTO || var == QHEA_BWD_ZTRI);
+    const bool zok = zyz_eligible(n, sh.E) && n != QHEA_EXP_N &&
+                     (var == QHEA_BWD_AUTO || var == QHEA_BWD_ZTRI || var == QHEA_BWD_ZPACKED);
     // Measured at cfg 2's circuit (us per call incl. prep / reduce; first-generation / ZYZ form):
-    //   forward   B = 1024 58 / 47,  4096 95 / 96,  16384 266 / 290: the ZYZ forward keeps 22 KB of LDS per wave (whole
-    //             (cos, sin) table + record ring), which caps the waves per CU once the batch could fill them
-    //   backward  B = 1024 packed 186, tri 134, ztri 115;  2048 257 / 261 / 221;  4096 319 / 408 / 421
-    // so AUTO takes the ZYZ forward up to two waves per SIMD and the ZYZ pipeline up to one sample group per SIMD.
-    if (var == QHEA_BWD_AUTO && zok && !L.lds_bwd && n <= 5 && B > 0) L.pair = L.nwaves_fwd <= (long)simd_count();
-    if (L.pair) L.nwaves = (B + spw - 1) / spw;
-    L.zfwd = zok && (var == QHEA_BWD_ZTRI || L.nwaves_fwd <= 2L * simd_count());
+    //   forward   B = 1024 55 / 44,  4096 87 / 89,  16384 236 / 255 with a record ring per wave (22 KB of LDS per wave
+    //             cap the waves per CU once the batch could fill them) -> one ring per workgroup beyond one wave per SIMD
+    //   backward  B = 1024 packed 189, tri 135, ztri 115, zpacked 173;  2048 251 / 255 / 208 / 180;
+    //             4096 302 / 400 / 402 / 258;  16384 1159 / 1405 / 1580 / 846   (scripts/ablate/bsweep_all.py)
+    // so AUTO keeps round 1's rule for the pipeline (sample groups on at most 3/4 of the SIMDs) and takes the one-wave
+    // ZYZ kernel beyond.
+    const bool fast = zok && zyz_fast_ld(sh.runs, n) != 0;
+    // forward: private-ring kernel while the sweeps leave SIMDs free, shared-ring kernel (block-unrolled shapes) beyond;
+    // other shapes fall back to the first-generation forward once two waves per SIMD are reached
+    L.zfwd_shared = fast && (var == QHEA_BWD_ZPACKED || (var == QHEA_BWD_AUTO && L.nwaves_fwd > (long)simd_count()));
+    L.zfwd = zok && (L.zfwd_shared || var == QHEA_BWD_ZTRI || L.nwaves_fwd <= 2L * simd_count());
     L.ztri = zok && L.pair;
+    // batches that fill the SIMDs: the one-wave ZYZ kernel for the block-unrolled shapes (B = 16384 at cfg 2's circuit:
+    // see DESIGN.md section 3.5), the first-generation packed kernel otherwise
+    const bool zp_ok = zyz_eligible(n, sh.E) && n != QHEA_EXP_N && zyz_fast_ld(sh.runs, n) != 0 && !L.lds_bwd;
+    L.zpacked = zp_ok && ((var == QHEA_BWD_AUTO && !L.pair) || var == QHEA_BWD_ZPACKED);
+    if (L.zpacked) {
+        L.pair = false; L.ztri = false;
+        L.nwaves = ((B + spw - 1) / spw + kZPWaves - 1) / kZPWaves * kZPWaves;      // one partial row per wave, padding waves write zeros
+    }
     L.zL = zok ? zyz_layer_count(sh.runs, n) : 0;
     size_t p = kHeaderBytes;                         // WorkspaceHeader
     L.off_U = p;    p = align_up(p + (size_t)(sh.blk + 2) * n * kGateBytes);
@@ -437,6 +451,18 @@ int launch_zyz_forward(int n, const Shape& sh, int64_t B, const Layout& L, char*
     for (int i = 0; i < sh.runs.nruns; ++i) nblocks += sh.runs.count[i];
     const ZFwdArgs za{sh.runs, (long)B, (int)sh.E, ws + L.off_rec, (int)((L.zL + 1) * kRecBytes), L.zL, src, off, co, diag,
                       pauli, out, state_out, bias, fast, nblocks};
+    if (L.zfwd_shared) {
+        const long groups = (B + (64 >> n) - 1) / (64 >> n);
+        const dim3 gs((unsigned)((groups + kZPWaves - 1) / kZPWaves));
+        const size_t dyns = (size_t)kZPWaves * (64 >> n) * zyz_cs_row(n, sh.E) * sizeof(double2);
+        switch (n) {
+#define QHEA_CASE(NN) case NN: launch_fwd_zshared_##NN(gs, dyns, st, za); break;
+            QHEA_FOR_EACH_ZN(QHEA_CASE)
+#undef QHEA_CASE
+            default: return QHEA_EUNSUPPORTED;
+        }
+        return QHEA_OK;
+    }
     const dim3 grid((unsigned)(L.nwaves_fwd / kWaves));
     const size_t dyn = (size_t)kWaves * (64 >> n) * zyz_cs_row(n, sh.E) * sizeof(double2);
     switch (n) {
@@ -457,6 +483,15 @@ int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char
                       diag, pauli, g, state_in, y, bias, inv_bt, out, grad_x, partial,
                       &reinterpret_cast<WorkspaceHeader*>(ws)->status, fast, nblocks};
     const size_t dyn = (size_t)(64 >> n) * zyz_cs_row(n, sh.E) * sizeof(double2);
+    if (L.zpacked) {
+        switch (n) {
+#define QHEA_CASE(NN) case NN: launch_bwd_zpacked_##NN(dim3((unsigned)(L.nwaves / kZPWaves)), dyn * kZPWaves, st, za); break;
+            QHEA_FOR_EACH_ZN(QHEA_CASE)
+#undef QHEA_CASE
+            default: return QHEA_EUNSUPPORTED;
+        }
+        return QHEA_OK;
+    }
     switch (n) {
 #define QHEA_CASE(NN) case NN: launch_bwd_ztri_##NN(dim3((unsigned)L.nwaves), dyn, st, za); break;
         QHEA_FOR_EACH_ZN(QHEA_CASE)
@@ -739,7 +774,7 @@ int qhea_profile_next_circuit_kernel(void* start_event, void* stop_event) {
 }
 
 int qhea_set_backward_variant(int variant) {
-    if (variant < QHEA_BWD_AUTO || variant > QHEA_BWD_ZTRI) return QHEA_EINVAL;
+    if (variant < QHEA_BWD_AUTO || variant > QHEA_BWD_ZPACKED) return QHEA_EINVAL;
     g_bwd_variant.store(variant, std::memory_order_relaxed);
     return QHEA_OK;
 }
@@ -834,7 +869,7 @@ int qhea_backward(int n_qubits, int n_blocks, const int32_t* enc_per_block, cons
     if (!workspace || workspace_bytes < L.total) return QHEA_EWORKSPACE;
     char* ws = static_cast<char*>(workspace);
     double* partial = reinterpret_cast<double*>(ws + L.off_part);
-    if (L.ztri) {
+    if (L.ztri || L.zpacked) {
         rc = launch_prep_zyz(n_qubits, sh, w, ws, L, st);
         if (rc != QHEA_OK) return rc;
         profile_begin(st);
@@ -962,7 +997,7 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
     const int kw = padded_3n(mi.n);
     const int nb_w = (int)((mi.sh.blk * kw + red_cols(kw) - 1) / red_cols(kw));
     const int nb_x = mi.trainable ? (int)((mi.sh.E + kFreqCols - 1) / kFreqCols) : 0;
-    if (M.L.ztri) {
+    if (M.L.ztri || M.L.zpacked) {
         rc = launch_prep_zyz(mi.n, mi.sh, params + mi.off_ans, ws, M.L, st);
         if (rc != QHEA_OK) return rc;
         profile_begin(st);

@@ -51,9 +51,17 @@ void QHEA_CAT(launch_fwd_zyz_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st
 void QHEA_CAT(launch_bwd_ztri_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a) {
     hipLaunchKernelGGL(bwd_ztri_kernel<QHEA_N>, grid, dim3(128 + 64 * kZSigma), dyn_lds, st, a);
 }
+void QHEA_CAT(launch_fwd_zshared_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArgs& a) {
+    hipLaunchKernelGGL(fwd_zshared_kernel<QHEA_N>, grid, dim3(kZPWaves * 64), dyn_lds, st, a);
+}
+void QHEA_CAT(launch_bwd_zpacked_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a) {
+    hipLaunchKernelGGL(bwd_zpacked_kernel<QHEA_N>, grid, dim3(kZPWaves * 64), dyn_lds, st, a);
+}
 #elif QHEA_N <= 5      // layout-experiment build: the ZYZ kernels need the all-lane layout and are never selected
 void QHEA_CAT(launch_fwd_zyz_, QHEA_N)(dim3, size_t, hipStream_t, const ZFwdArgs&) {}
 void QHEA_CAT(launch_bwd_ztri_, QHEA_N)(dim3, size_t, hipStream_t, const ZBwdArgs&) {}
+void QHEA_CAT(launch_bwd_zpacked_, QHEA_N)(dim3, size_t, hipStream_t, const ZBwdArgs&) {}
+void QHEA_CAT(launch_fwd_zshared_, QHEA_N)(dim3, size_t, hipStream_t, const ZFwdArgs&) {}
 #endif
 
 }  // namespace qhea

@@ -265,9 +265,15 @@ constexpr int kBSlots = 4, kBDist = 2;         // block slots per ring; blocks i
 constexpr int kPadRecs = 9;                    // >= (kBDist + 1) * 3 records of padding before record 0 and after record L
 constexpr int kBlockRingBytes = kBSlots * 3 * kRecBytes;     // per streaming wave (LD = 2)
 
-template <int N, int LD>
+// SHARED = false: the ring is private to the wave (chains of the pipeline kernel, forward kernel).
+// SHARED = true:  one ring per workgroup, filled by its wave 0 (`loader`); every wave of the workgroup walks the same
+//                 records block by block, so ONE barrier per block orders both "block b+1 has landed" and "everybody is
+//                 done with the slot about to be overwritten" (bwd_zpacked_kernel: at large batches the LDS a wave
+//                 needs decides how many waves a CU holds).
+template <int N, int LD, bool SHARED = false>
 struct BlockStream {
     static constexpr int RPB = 1 + LD;
+    bool loader = true;
     u32x4 rsrc;                 // starts kPadRecs records before record 0
     char* ring;
     unsigned lds0, lane16, a_dg;
@@ -297,13 +303,32 @@ struct BlockStream {
     __device__ __forceinline__ const char* slot(int b) const { return ring + (b & (kBSlots - 1)) * (RPB * kRecBytes); }
     // Per block: landed<D>() at the top (blocks b+D .. b+kBDist*D are in flight, b+D must have landed), ahead<D>(b)
     // later in the block -- in the latency shadow of a ring gather -- fetches block b + (kBDist+1) D.
-    __device__ __forceinline__ void landed() const { wait_vmcnt<(kBDist - 1) * RPB>(); }
+    __device__ __forceinline__ void landed() const {
+        if (!SHARED || loader) wait_vmcnt<(kBDist - 1) * RPB>();
+        if constexpr (SHARED) __syncthreads();
+    }
     template <int D>
-    __device__ __forceinline__ void ahead(int b) const { issue(b + (kBDist + 1) * D); }
+    __device__ __forceinline__ void ahead(int b) const { if (!SHARED || loader) issue(b + (kBDist + 1) * D); }
     template <int D>
     __device__ __forceinline__ void step(int b) const {              // both at once (priming)
         ahead<D>(b);
-        wait_vmcnt<kBDist * RPB>();
+        if (!SHARED || loader) wait_vmcnt<kBDist * RPB>();
+        if constexpr (SHARED) __syncthreads();
+    }
+    // start a walk at block b0 in direction D: b0 landed, b0+D .. b0+kBDist*D in flight.  `drain`: fetches of a previous
+    // walk may still be in flight towards the same slots
+    template <int D>
+    __device__ __forceinline__ void prime(int b0, bool drain) const {
+        if (!SHARED || loader) {
+            if (drain) wait_vmcnt<0>();
+        }
+        if constexpr (SHARED) { if (drain) __syncthreads(); }        // nobody still reads the slots of the previous walk
+        if (!SHARED || loader) {
+#pragma unroll
+            for (int i = 0; i <= kBDist; ++i) issue(b0 + i * D);
+            wait_vmcnt<kBDist * RPB>();
+        }
+        if constexpr (SHARED) __syncthreads();
     }
     static __device__ __forceinline__ double2 rd(const char* p, unsigned off) { return *reinterpret_cast<const double2*>(p + off); }
     __device__ __forceinline__ void load_records(const char* sl) {
@@ -328,15 +353,12 @@ __host__ __device__ inline int zyz_fast_ld(const Runs& r, int n) {      // LD of
     return ld;
 }
 
-template <int N, int LD>
-__device__ __forceinline__ void zyz_forward_fast(double (&re)[1], double (&im)[1], const Runs& runs, BlockStream<N, LD>& bs,
+template <int N, int LD, class BS>
+__device__ __forceinline__ void zyz_forward_fast(double (&re)[1], double (&im)[1], const Runs& runs, BS& bs,
                                                  const double2* __restrict__ csrow, int E, int lane, int klow, int ring_fwd) {
-    constexpr int RPB = 1 + LD;
     re[0] = klow == 0 ? 1.0 : 0.0;
     im[0] = 0.0;
-#pragma unroll
-    for (int i = 0; i <= kBDist; ++i) bs.issue(i);
-    wait_vmcnt<kBDist * RPB>();
+    bs.template prime<1>(0, false);
     bs.load_records(bs.slot(0));
     bs.load_cs(csrow, 0);
     int b = 0, col = 0;
@@ -514,13 +536,10 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
 
     if constexpr (MODE != 0) {
         // ---- block-unrolled reverse walk: per block  ring^-1 publish RY(b,LD)^-1 [dg(b,LD)]^-1 ... [dg(b,1)]^-1 publish RX(b)^-1 [dg(b,0)]^-1
-        constexpr int LD = MODE, RPB = 1 + LD;
+        constexpr int LD = MODE;
         const int nb = a.nblocks;
-        wait_vmcnt<0>();                                      // the forward sweep's run-ahead fetches target the same slots
-#pragma unroll
-        for (int i = 0; i <= kBDist; ++i) bs.issue(nb - i);
-        wait_vmcnt<kBDist * RPB>();                           // block nb's slot: its record 0 is the final diagonal
-        apply_phase<true>(sr[0], si[0], bs.rd(bs.slot(nb), bs.a_dg));
+        bs.template prime<-1>(nb, true);                      // (drain: the forward sweep's run-ahead fetches target the same slots)
+        apply_phase<true>(sr[0], si[0], bs.rd(bs.slot(nb), bs.a_dg));     // block nb's slot: its record 0 is the final diagonal
         bs.template step<-1>(nb);                             // block nb-1 landed
         bs.load_records(bs.slot(nb - 1));
         int bl = nb - 1, col = E;
@@ -726,6 +745,217 @@ __global__ __launch_bounds__(128 + 64 * kZSigma) void bwd_ztri_kernel(ZBwdArgs a
     report_abort(&sync.abort, a.status, lane);
 }
 
+// ---------------------------------------------------------------------------------------
+// One-wave-per-sample-group backward kernel in the ZYZ form, for batches that fill the SIMDs (AUTO: more sample
+// groups than SIMDs; block-unrolled shapes only, others keep bwd_kernel of hea_device.hpp).  At those batches the
+// first-generation packed kernel is bound by the CU's single LDS pipe (per sample group and block ~170 LDS
+// instructions: gate-table reads for three sweeps, sums staged through LDS, ds_swizzle exchanges), so this kernel
+// spends vector instructions instead, which have headroom there:
+//   * psi and lambda are walked back together and share every coefficient read; the DPP exchange of psi that a gate's
+//     inverse needs also feeds that qubit's inner products (gates of a layer commute, so X,Y,Z of qubit q may be
+//     taken when the other qubits' gates are already undone on both states);
+//   * gradient sums by the register butterfly (pair sums over lane bits 4, 5 through permlane swaps), not through LDS;
+//   * one record ring per WORKGROUP (BlockStream<SHARED>): 12 KB + 4 x 10 KB of (cos, sin) tables = 52 KB per four
+//     waves, so three workgroups (12 waves) fit a CU.
+// Only wire 4's partner fetch for the inner products (4 ds_swizzle per layer) and the ring gathers use the LDS pipe.
+// ---------------------------------------------------------------------------------------
+constexpr int kZPWaves = 4;
+
+// psi <- RY_Q^-1 psi, lambda <- RY_Q^-1 lambda, and this lane's terms of X,Y,Z = Im<lambda|sigma_Q|psi> taken before
+template <int Q>
+__device__ __forceinline__ void ry_inv_with_inner(double& pr, double& pi, double& lr, double& li, const double2& u, int lane,
+                                                  double& X, double& Y, double& Z) {
+    const double sg = ((lane >> Q) & 1) ? -1.0 : 1.0;
+    if constexpr (Q == 4) {
+        const double qr = xchg<16>(pr), qi = xchg<16>(pi);
+        X = lr * qi - li * qr;
+        Y = -sg * (lr * qr + li * qi);
+        Z = sg * (lr * pi - li * pr);
+        apply_ry<4, true>(pr, pi, u);
+        apply_ry<4, true>(lr, li, u);
+    } else {
+        const double qr = xchg<(1 << Q)>(pr), qi = xchg<(1 << Q)>(pi);
+        X = lr * qi - li * qr;
+        Y = -sg * (lr * qr + li * qi);
+        Z = sg * (lr * pi - li * pr);
+        pr = u.x * pr - u.y * qr;                 // RY^-1: sv -> -sv
+        pi = u.x * pi - u.y * qi;
+        apply_ry<Q, true>(lr, li, u);
+    }
+}
+// the same for an encoding gate (apply_enc): its gradient is the X inner product (wires 0..3) or the Y one (wire 4)
+template <int N, int Q>
+__device__ __forceinline__ void enc_inv_with_inner(double (&pr)[1], double (&pi)[1], double (&lr)[1], double (&li)[1],
+                                                   const double2& cs, int lane, double& G) {
+    if constexpr (Q == 4) {
+        const double sg = ((lane >> Q) & 1) ? -1.0 : 1.0;
+        const double qr = xchg<16>(pr[0]), qi = xchg<16>(pi[0]);
+        G = -sg * (lr[0] * qr + li[0] * qi);
+        apply_ry<4, true>(pr[0], pi[0], cs);
+        apply_ry<4, true>(lr[0], li[0], cs);
+    } else {
+        const double qr = xchg<(1 << Q)>(pr[0]), qi = xchg<(1 << Q)>(pi[0]);
+        G = lr[0] * qi - li[0] * qr;
+        const double nr = cs.x * pr[0] - cs.y * qi;       // RX^-1: s -> -s in (c p + s q_i, c p_i - s q_r)
+        pi[0] = cs.x * pi[0] + cs.y * qr;
+        pr[0] = nr;
+        apply_rx<N, Q>(lr, li, cs.x, -cs.y);
+    }
+}
+
+template <int N, int LD>
+__device__ __forceinline__ void zpacked_body(const ZBwdArgs& a, int wib, int lane, int klow, bool valid, long b, long wave,
+                                             const double2* cs, char* wg_ring) {
+    using C = Cfg<N>;
+    const int E = a.E;
+    const int ring_fwd = ring_source<N>(lane, false);
+    const int ring_rev = ring_source<N>(lane, true);
+    const double2* csrow = cs + (wib * C::SPW + (lane >> C::LB)) * (int)zyz_cs_row(N, E) + N;
+    BlockStream<N, LD, true> bs;
+    bs.init(a.rec, a.L + 1, wg_ring, lane, klow);
+    bs.loader = wib == 0;
+
+    double pr[1], pi[1], lr[1], li[1];
+    if (a.state_in) {
+        const double2 s0 = reinterpret_cast<const double2*>(a.state_in)[(b << N) + klow];
+        pr[0] = s0.x; pi[0] = s0.y;
+    } else {
+        zyz_forward_fast<N, LD>(pr, pi, a.runs, bs, csrow, E, lane, klow, ring_fwd);
+    }
+    {   // upstream weight and lambda_N = g H psi_N (in the read-out basis, then rotated back)
+        double fr[1] = {pr[0]}, fi[1] = {pi[0]};
+        basis_change<N, false>(fr, fi, a.pauli, lane);
+        const double h = ham_weight<N>(klow, a.off, a.co, a.diag);
+        double v[1] = {h * (fr[0] * fr[0] + fi[0] * fi[0])};
+        lane_reduce<1, C::LB>(v, lane);
+        const double pred = v[0] + (a.bias ? a.bias[0] : 0.0);
+        if (a.out && valid && klow == 0) a.out[b] = pred;
+        double gb = a.y ? 2.0 * (pred - a.y[b]) * a.inv_bt : a.g[b];
+        if (!valid) gb = 0.0;
+        lr[0] = gb * h * fr[0]; li[0] = gb * h * fi[0];
+        basis_change<N, true>(lr, li, a.pauli, lane);
+    }
+
+    const int nb = a.nblocks;
+    bs.template prime<-1>(nb, true);
+    {
+        const double2 d = bs.rd(bs.slot(nb), bs.a_dg);         // record L: the final diagonal
+        apply_phase<true>(pr[0], pi[0], d);
+        apply_phase<true>(lr[0], li[0], d);
+    }
+    bs.template step<-1>(nb);
+    bs.load_records(bs.slot(nb - 1));
+    int bl = nb - 1, col = E, sub = a.blk;
+    bs.load_cs(csrow, col - N);
+    double* __restrict__ part_w = a.partial + wave * (long)a.blk * C::KW;
+    for (int ri = a.runs.nruns - 1; ri >= 0; --ri) {
+        for (int rep = 0; rep < a.runs.count[ri]; ++rep) {
+            bs.landed();
+            const char* nx = bs.slot(bl - 1);
+#pragma unroll
+            for (int s = LD - 1; s >= 0; --s) {
+                if (s != LD - 1) {
+                    apply_phase<true>(pr[0], pi[0], bs.dg[s + 2]);
+                    apply_phase<true>(lr[0], li[0], bs.dg[s + 2]);
+                    bs.dg[s + 2] = bs.rd(nx, (s + 2) * kRecBytes + bs.a_dg);
+                }
+                pr[0] = lane_gather(pr[0], ring_rev); pi[0] = lane_gather(pi[0], ring_rev);
+                lr[0] = lane_gather(lr[0], ring_rev); li[0] = lane_gather(li[0], ring_rev);
+                if (s == LD - 1) bs.template ahead<-1>(bl);
+                --sub;
+                double acc3[C::KW];
+#pragma unroll
+                for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
+                static_rfor<0, N>([&](auto q) {
+                    constexpr int Q = decltype(q)::value;
+                    ry_inv_with_inner<Q>(pr[0], pi[0], lr[0], li[0], bs.ry[s][Q], lane, acc3[3 * Q], acc3[3 * Q + 1], acc3[3 * Q + 2]);
+                    bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
+                });
+                lane_reduce<C::KW, 6>(acc3, lane);
+                if (lane < C::KW) part_w[(long)sub * C::KW + lane] = acc3[0];
+            }
+            apply_phase<true>(pr[0], pi[0], bs.dg[1]);
+            apply_phase<true>(lr[0], li[0], bs.dg[1]);
+            bs.dg[1] = bs.rd(nx, kRecBytes + bs.a_dg);
+            col -= N;
+            const double2* cn = csrow + (col - N);
+            double gx[C::KX];
+#pragma unroll
+            for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
+            static_rfor<0, N>([&](auto q) {
+                constexpr int Q = decltype(q)::value;
+                enc_inv_with_inner<N, Q>(pr, pi, lr, li, bs.cs[Q], lane, gx[Q]);
+                bs.cs[Q] = cn[Q];
+            });
+            store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, col, N);
+            apply_phase<true>(pr[0], pi[0], bs.dg[0]);
+            apply_phase<true>(lr[0], li[0], bs.dg[0]);
+            bs.dg[0] = bs.rd(nx, bs.a_dg);
+            --bl;
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(kZPWaves * 64) void bwd_zpacked_kernel(ZBwdArgs a) {
+    using C = Cfg<N>;
+    static_assert(C::R == 1, "all-lane layout");
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // kZPWaves x SPW x (E + 2N) (cos, sin)
+    __shared__ __attribute__((aligned(16))) char wg_ring[kBlockRingBytes];          // ONE record ring per workgroup
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long wave = (long)blockIdx.x * kZPWaves + wib;
+    const long b_raw = wave * C::SPW + (lane >> C::LB);
+    const bool valid = b_raw < a.B;
+    const long b = valid ? b_raw : a.B - 1;
+    const int klow = lane & (C::LANES - 1);
+    double2* cs = reinterpret_cast<double2*>(dyn_lds);
+    fill_cs(cs, a.src, N, a.E, (long)blockIdx.x * kZPWaves * C::SPW, a.B, kZPWaves * C::SPW, (int)threadIdx.x, kZPWaves * 64);
+    __syncthreads();
+    if (a.fast_ld == 2) zpacked_body<N, 2>(a, wib, lane, klow, valid, b, wave, cs, wg_ring);
+    else zpacked_body<N, 1>(a, wib, lane, klow, valid, b, wave, cs, wg_ring);
+}
+
+// Forward-only counterpart for batches that fill the SIMDs: four sweeping waves per workgroup on ONE shared record ring
+// (52 KB per workgroup at cfg 2 instead of 44 KB per two sweeping waves: twice the resident sweeps per CU).
+template <int N>
+__global__ __launch_bounds__(kZPWaves * 64) void fwd_zshared_kernel(ZFwdArgs a) {
+    using C = Cfg<N>;
+    static_assert(C::R == 1, "all-lane layout");
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    __shared__ __attribute__((aligned(16))) char wg_ring[kBlockRingBytes];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long wave = (long)blockIdx.x * kZPWaves + wib;
+    const long b_raw = wave * C::SPW + (lane >> C::LB);
+    const bool valid = b_raw < a.B;
+    const long b = valid ? b_raw : a.B - 1;
+    const int klow = lane & (C::LANES - 1);
+    const int ring_fwd = ring_source<N>(lane, false);
+    double2* cs = reinterpret_cast<double2*>(dyn_lds);
+    fill_cs(cs, a.src, N, a.E, (long)blockIdx.x * kZPWaves * C::SPW, a.B, kZPWaves * C::SPW, (int)threadIdx.x, kZPWaves * 64);
+    __syncthreads();
+    const double2* csrow = cs + (wib * C::SPW + (lane >> C::LB)) * (int)zyz_cs_row(N, a.E) + N;
+    double re[1], im[1];
+    if (a.fast_ld == 2) {
+        BlockStream<N, 2, true> bs;
+        bs.init(a.rec, a.L + 1, wg_ring, lane, klow);
+        bs.loader = wib == 0;
+        zyz_forward_fast<N, 2>(re, im, a.runs, bs, csrow, a.E, lane, klow, ring_fwd);
+    } else {
+        BlockStream<N, 1, true> bs;
+        bs.init(a.rec, a.L + 1, wg_ring, lane, klow);
+        bs.loader = wib == 0;
+        zyz_forward_fast<N, 1>(re, im, a.runs, bs, csrow, a.E, lane, klow, ring_fwd);
+    }
+    if (a.state_out && valid)
+        reinterpret_cast<double2*>(a.state_out)[(b << N) + klow] = make_double2(re[0], im[0]);
+    basis_change<N, false>(re, im, a.pauli, lane);
+    double v[1] = {ham_weight<N>(klow, a.off, a.co, a.diag) * (re[0] * re[0] + im[0] * im[0])};
+    lane_reduce<1, C::LB>(v, lane);
+    if (valid && klow == 0) a.out[b] = v[0] + (a.bias ? a.bias[0] : 0.0);
+}
+
 // launch entry points (hea_inst.hip, n <= 5 only)
 #ifdef QHEA_ZSUBSET     // development / test builds link a subset of the qubit counts (see the Makefile)
 #define QHEA_FOR_EACH_ZN(X) QHEA_ZSUBSET(X)
@@ -734,7 +964,9 @@ __global__ __launch_bounds__(128 + 64 * kZSigma) void bwd_ztri_kernel(ZBwdArgs a
 #endif
 #define QHEA_ZDECLARE(NN)                                                              \
     void launch_fwd_zyz_##NN(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArgs& a); \
-    void launch_bwd_ztri_##NN(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a);
+    void launch_fwd_zshared_##NN(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArgs& a); \
+    void launch_bwd_ztri_##NN(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a);   \
+    void launch_bwd_zpacked_##NN(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a);
 QHEA_FOR_EACH_ZN(QHEA_ZDECLARE)
 #undef QHEA_ZDECLARE
 

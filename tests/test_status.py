@@ -95,7 +95,7 @@ def test_status_is_clean_after_healthy_runs():
     rng = np.random.default_rng(1)
     x = torch.tensor(rng.uniform(-3, 3, (200, 10)), device=dev); w = torch.tensor(rng.uniform(-3, 3, (4, 3, 5)), device=dev)
     g = torch.ones(200, dtype=torch.float64, device=dev)
-    for v in ('ztri', 'tri', 'pair', 'packed', 'auto'):
+    for v in ('ztri', 'zpacked', 'tri', 'pair', 'packed', 'auto'):
         _lib.set_backward_variant(v)
         for _ in range(20):
             gx, gw = _lib.hea_backward(sh, x, w, g, 0.0, 1.0)
