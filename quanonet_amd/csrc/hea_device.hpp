@@ -195,6 +195,69 @@ __device__ __forceinline__ void lane_reduce(double (&v)[K], int lane) {
     }
 }
 
+// Whole-wave sums of K = 8 or 16 values per lane with the transposing butterfly taken in the CHEAPEST order of lane
+// bits.  A transposing step on lane bit t halves the live values: lanes with bit t = 0 end with own + partner of the
+// even value of each pair, lanes with bit t = 1 of the odd one.  On bits 0..3 that costs 7 instructions per pair
+// (4 selects, 2 DPP moves, 1 add: lane_reduce above); but
+//   bit 4: v_permlane16_swap_b32 (A, B) swaps the odd 16-lane rows of A with the even rows of B -- afterwards A + B IS
+//          the transposed pair sum: 2 swaps + 1 add per pair, no select;
+//   bit 5: v_permlane32_swap_b32 likewise on the wave's halves;
+//   bits 3, 2: two bank-masked DPP moves per 32-bit word (row_shr / row_shl by 8 or 4 into the lanes whose bit is 1 / 0,
+//          the other lanes keep the old value) build (own A | partner's B) and (partner's A | own B): 4 moves + 1 add.
+// So the steps with many pairs go to bits 4 and 5: 16 values cost 8*3 + 4*3 + 2*5 + 1*5 + 2*3 = 57 instructions
+// instead of 111.  Returns the index of the value whose 64-lane total this lane holds in v[0]; lanes whose remaining
+// low bits are zero are the ones that should store it (`butterfly_owner`).
+template <int K>
+__device__ __forceinline__ int butterfly_sum(double (&v)[K], int lane) {
+    static_assert(K == 8 || K == 16, "K");
+    auto swap_level = [&](int c, auto which) {              // c live values -> c/2; bit 4 (which = 16) or bit 5 (32)
+#pragma unroll
+        for (int i = 0; i < K / 2; ++i) {
+            if (i < c / 2) {
+                const unsigned alo = (unsigned)__double2loint(v[2 * i]), ahi = (unsigned)__double2hiint(v[2 * i]);
+                const unsigned blo = (unsigned)__double2loint(v[2 * i + 1]), bhi = (unsigned)__double2hiint(v[2 * i + 1]);
+                if constexpr (decltype(which)::value == 16) {
+                    const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+                    const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+                    v[i] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+                } else {
+                    const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+                    const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+                    v[i] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+                }
+            }
+        }
+    };
+    swap_level(K, std::integral_constant<int, 16>{});
+    swap_level(K / 2, std::integral_constant<int, 32>{});
+    // bit 3 (xor 8): row_shr:8 = 0x118 into banks 2,3; row_shl:8 = 0x108 into banks 0,1
+#pragma unroll
+    for (int i = 0; i < K / 8; ++i) {
+        const int alo = __double2loint(v[2 * i]), ahi = __double2hiint(v[2 * i]);
+        const int blo = __double2loint(v[2 * i + 1]), bhi = __double2hiint(v[2 * i + 1]);
+        const int a2lo = __builtin_amdgcn_update_dpp(alo, blo, 0x118, 0xF, 0xC, false), a2hi = __builtin_amdgcn_update_dpp(ahi, bhi, 0x118, 0xF, 0xC, false);
+        const int b2lo = __builtin_amdgcn_update_dpp(blo, alo, 0x108, 0xF, 0x3, false), b2hi = __builtin_amdgcn_update_dpp(bhi, ahi, 0x108, 0xF, 0x3, false);
+        v[i] = __hiloint2double(a2hi, a2lo) + __hiloint2double(b2hi, b2lo);
+    }
+    int idx = ((lane >> 4) & 1) | (((lane >> 5) & 1) << 1) | (((lane >> 3) & 1) << 2);
+    if constexpr (K == 16) {
+        // bit 2 (xor 4): row_shr:4 = 0x114 into banks 1,3; row_shl:4 = 0x104 into banks 0,2
+        const int alo = __double2loint(v[0]), ahi = __double2hiint(v[0]);
+        const int blo = __double2loint(v[1]), bhi = __double2hiint(v[1]);
+        const int a2lo = __builtin_amdgcn_update_dpp(alo, blo, 0x114, 0xF, 0xA, false), a2hi = __builtin_amdgcn_update_dpp(ahi, bhi, 0x114, 0xF, 0xA, false);
+        const int b2lo = __builtin_amdgcn_update_dpp(blo, alo, 0x104, 0xF, 0x5, false), b2hi = __builtin_amdgcn_update_dpp(bhi, ahi, 0x104, 0xF, 0x5, false);
+        v[0] = __hiloint2double(a2hi, a2lo) + __hiloint2double(b2hi, b2lo);
+        idx |= ((lane >> 2) & 1) << 3;
+    } else {
+        v[0] = pair_sum<4>(v[0]);
+    }
+    v[0] = pair_sum<2>(v[0]);
+    v[0] = pair_sum<1>(v[0]);
+    return idx;
+}
+template <int K>
+__device__ __forceinline__ bool butterfly_owner(int lane) { return (lane & (K == 16 ? 3 : 7)) == 0; }
+
 // Sums through a wave-private LDS scratch (rows of kRedStride doubles, one row per value, one column
 // per lane).  Far fewer vector-ALU instructions than the register butterfly: K stores, K/2 wide loads,
 // K adds and log2(64/K) exchange-adds.  The wave reads only what it wrote itself (LDS is in-order per

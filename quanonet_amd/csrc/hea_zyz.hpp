@@ -710,8 +710,8 @@ __global__ __launch_bounds__(128 + 64 * kZSigma) void bwd_ztri_kernel(ZBwdArgs a
                         acc3[3 * Q + 1] = -sg * (lm.x * qv[Q].x + lm.y * qv[Q].y);
                         acc3[3 * Q + 2] = sg * (lm.x * p.y - lm.y * p.x);
                     });
-                    lane_reduce<C::KW, 6>(acc3, lane);
-                    if (lane < C::KW) part_w[(long)sub * C::KW + lane] = acc3[0];
+                    const int vi = butterfly_sum<C::KW>(acc3, lane);
+                    if (butterfly_owner<C::KW>(lane)) part_w[(long)sub * C::KW + vi] = acc3[0];
                 }
                 for (int ch = nch - 1; ch >= 0; --ch) {
                     const int m = ch == nch - 1 ? m_last : N;
@@ -871,8 +871,8 @@ __device__ __forceinline__ void zpacked_body(const ZBwdArgs& a, int wib, int lan
                     ry_inv_with_inner<Q>(pr[0], pi[0], lr[0], li[0], bs.ry[s][Q], lane, acc3[3 * Q], acc3[3 * Q + 1], acc3[3 * Q + 2]);
                     bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
                 });
-                lane_reduce<C::KW, 6>(acc3, lane);
-                if (lane < C::KW) part_w[(long)sub * C::KW + lane] = acc3[0];
+                const int vi = butterfly_sum<C::KW>(acc3, lane);
+                if (butterfly_owner<C::KW>(lane)) part_w[(long)sub * C::KW + vi] = acc3[0];
             }
             apply_phase<true>(pr[0], pi[0], bs.dg[1]);
             apply_phase<true>(lr[0], li[0], bs.dg[1]);
