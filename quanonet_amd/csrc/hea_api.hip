@@ -209,14 +209,18 @@ struct AdamArgs {
     double* p; double* m; double* v;           // p == nullptr: no update (plain qhea_model_loss_grad)
     double lr_over_bc1, inv_sqrt_bc2, b1, b2, eps, wd;
 };
-__device__ __forceinline__ void adam_update(const AdamArgs& a, long i, double gi) {
-    const double pi = a.p[i];
+// (pi, m0, v0 = the element's current parameter and moments: callers that know early which element they will update
+// load them BEFORE their long reduction, so that the update does not add a dependent memory round trip at the end)
+__device__ __forceinline__ void adam_update_pre(const AdamArgs& a, long i, double gi, double pi, double m0, double v0) {
     if (a.wd != 0.0) gi += a.wd * pi;
-    const double mi = a.b1 * a.m[i] + (1.0 - a.b1) * gi;         // torch: exp_avg.lerp_(grad, 1 - beta1)
-    const double vi = a.b2 * a.v[i] + (1.0 - a.b2) * gi * gi;    //        exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const double mi = a.b1 * m0 + (1.0 - a.b1) * gi;             // torch: exp_avg.lerp_(grad, 1 - beta1)
+    const double vi = a.b2 * v0 + (1.0 - a.b2) * gi * gi;        //        exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     a.m[i] = mi; a.v[i] = vi;
     const double denom = sqrt(vi) * a.inv_sqrt_bc2 + a.eps;
     a.p[i] = pi - a.lr_over_bc1 * (mi / denom);
+}
+__device__ __forceinline__ void adam_update(const AdamArgs& a, long i, double gi) {
+    adam_update_pre(a, i, gi, a.p[i], a.m[i], a.v[i]);
 }
 
 // grad_w[s,{0,1,2},q] from the per-wave (X,Y,Z) partial sums (column sums over waves of partial[wave][s][kw]).
@@ -230,6 +234,22 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
     const int j = threadIdx.x % cols, slice = threadIdx.x / cols;
     const long ncols = (long)blk * kw;
     const long v = (long)bid * cols + j;
+    // the thread that will finish gate (s, q) fetches what the finish needs first: gradient-map coefficients and the
+    // three angles' Adam state travel while the partial rows are being summed
+    const int s_fin = (int)(v / kw), r_fin = (int)(v % kw), q_fin = r_fin / 3;
+    const bool fin = slice == 0 && v < ncols && r_fin < 3 * n && r_fin % 3 == 0;
+    const bool upd = fin && adam && adam->p;
+    double gmv[6] = {1.0, 0.0, 1.0, 0.0, 1.0, 0.0}, ap[3] = {0, 0, 0}, am[3] = {0, 0, 0}, av[3] = {0, 0, 0};
+    if (fin && gmap) {
+        const double* gm = gmap + ((long)s_fin * n + q_fin) * kGmapDoubles;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gmv[i] = gm[i];
+    }
+    if (upd) {
+        const long base = adam_base + (long)s_fin * 3 * n + q_fin;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { ap[i] = adam->p[base + (long)i * n]; am[i] = adam->m[base + (long)i * n]; av[i] = adam->v[base + (long)i * n]; }
+    }
     acc[slice * cols + j] = v < ncols ? slice_sum(partial + v, nwaves, ncols, slice, nslices) : 0.0;
     __syncthreads();
     // slices are combined in two fixed-order stages (8 interleaved groups, then those 8): a quarter of the serial
@@ -257,9 +277,8 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
             const double* ws = w + (long)s * 3 * n;
             double sb, cb, sc, cc;
             if (gmap) {     // sums taken after the RY layer, before D_post = RZ(alpha): rotate (X, Y) by alpha (hea_zyz.hpp)
-                const double* gm = gmap + ((long)s * n + q) * kGmapDoubles;
-                cb = gm[0]; sb = gm[1]; cc = gm[2]; sc = gm[3];
-                const double ca = gm[4], sa = gm[5];
+                cb = gmv[0]; sb = gmv[1]; cc = gmv[2]; sc = gmv[3];
+                const double ca = gmv[4], sa = gmv[5];
                 const double Xr = ca * X - sa * Y;
                 Y = ca * Y + sa * X;
                 X = Xr;
@@ -273,11 +292,11 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
             gs[2 * n + q] = gc;
             gs[n + q] = gb;
             gs[q] = ga;
-            if (adam && adam->p && !poisoned) {  // this thread alone reads and writes the three angles of gate (s, q)
+            if (upd && !poisoned) {              // this thread alone reads and writes the three angles of gate (s, q)
                 const long base = adam_base + (long)s * 3 * n;
-                adam_update(*adam, base + 2 * n + q, gc);
-                adam_update(*adam, base + n + q, gb);
-                adam_update(*adam, base + q, ga);
+                adam_update_pre(*adam, base + 2 * n + q, gc, ap[2], am[2], av[2]);
+                adam_update_pre(*adam, base + n + q, gb, ap[1], am[1], av[1]);
+                adam_update_pre(*adam, base + q, ga, ap[0], am[0], av[0]);
             }
         }
     }
