@@ -139,7 +139,8 @@ __device__ inline LayerInfo decode_layer(const Runs& r, int n, int l) {
 // so that the reduce kernel does not spend five serial sincos per gate on them: gmap[s*n + q] = 8 doubles.
 constexpr int kGmapDoubles = 8;
 __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, const double* __restrict__ w,
-                                                      char* __restrict__ rec, double* __restrict__ gmap, WorkspaceHeader* hdr) {
+                                                      char* __restrict__ rec, char* __restrict__ srec,
+                                                      double* __restrict__ gmap, WorkspaceHeader* hdr) {
     const int l = blockIdx.x, j = threadIdx.x;
     if (l == 0 && j == 0) header_init(hdr);
     const LayerInfo cur = decode_layer(runs, n, l < L ? l : -1), prev = decode_layer(runs, n, l - 1);
@@ -174,11 +175,24 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
         if (n == 5 && cur.kind == 0 && cur.m == 5) ph = cmul(ph, make_double2(kR, one ? kR : -kR));
         if (n == 5 && prev.kind == 0 && prev.m == 5) ph = cmul(ph, make_double2(kR, one ? -kR : kR));
         reinterpret_cast<double2*>(out)[j] = ph;
+        if (srec) {     // split records (n = 5, hea_zyz.hpp): wires 0..3 of a full RX chunk run as RZ(-pi/2) RY RZ(pi/2) too
+            for (int q = 0; q < 4; ++q) {
+                const bool b1 = (j >> q) & 1;
+                if (cur.kind == 0 && cur.m == 5) ph = cmul(ph, make_double2(kR, b1 ? kR : -kR));
+                if (prev.kind == 0 && prev.m == 5) ph = cmul(ph, make_double2(kR, b1 ? -kR : kR));
+            }
+            double* d = reinterpret_cast<double*>(srec + (long)l * kRecBytes + j * 24);
+            d[0] = -ph.y; d[1] = ph.x; d[2] = ph.y;
+        }
     } else if (j >= 32 && j < 32 + 2 * n) {
         const int q = (j - 32) >> 1, var = (j - 32) & 1;
         double2 e = make_double2(1.0, 0.0);
         if (cur.kind == 1) e = make_double2(gz[0][q].c, var ? gz[0][q].s : -gz[0][q].s);
         *reinterpret_cast<double2*>(out + kRecRy + q * 32 + var * 16) = e;
+        if (srec) {     // wire 4: the swap form's variants (c, -s) / (s, c)
+            if (cur.kind == 1 && q == 4 && var == 1) e = make_double2(gz[0][q].s, gz[0][q].c);
+            *reinterpret_cast<double2*>(srec + (long)l * kRecBytes + kSRecRy + q * 32 + var * 16) = e;
+        }
     }
 }
 
@@ -344,12 +358,14 @@ int make_shape(int n, int nb, const int32_t* enc, const int32_t* ld, Shape& sh) 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t off_U, off_cs, off_part, off_rec, off_gmap, total;
+    size_t off_U, off_cs, off_part, off_rec, off_srec, off_gmap, total;
     long nwaves, nwaves_fwd;
     bool lds_fwd, lds_bwd, pair;
     bool zfwd, zfwd_shared, ztri, zpacked;   // ZYZ-form kernels of hea_zyz.hpp (n <= 5): forward (private / shared record ring),
                                              // pipelined backward, one-wave backward
     int zL;                 // their layer count (records 0 .. zL)
+    bool zsplit;            // n = 5, block-unrolled shape, table fits: split records exist (forward sweeps in the split layout)
+    bool zfwd_split;        // ... and the forward kernel is the split one (batches that leave SIMDs free; Z / diagonal read-out)
 };
 
 // Pipelined backward kernels (n <= 5): several waves per sample group (psi chain, lambda chain, sigma waves), so they
@@ -441,6 +457,11 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     L.off_part = p; p = align_up(p + (size_t)L.nwaves * sh.blk * padded_3n(n) * sizeof(double));
     L.off_rec = p;  p = align_up(p + (zok ? (size_t)(L.zL + 1 + 2 * kPadRecs) * kRecBytes : 0));   // padded both sides
     if (zok) L.off_rec += (size_t)kPadRecs * kRecBytes;                                           // -> record 0
+    L.zsplit = zok && zsplit_eligible(n, sh.E, sh.runs);
+    // one sample per wave: pays while every sweeping wave still gets a SIMD of its own
+    L.zfwd_split = L.zsplit && L.zfwd && !L.zfwd_shared && B <= (int64_t)simd_count();
+    L.off_srec = p; p = align_up(p + (L.zsplit ? (size_t)(L.zL + 1 + 2 * kPadRecs) * kRecBytes : 0));
+    if (L.zsplit) L.off_srec += (size_t)kPadRecs * kRecBytes;
     L.off_gmap = p; p = align_up(p + (zok ? (size_t)sh.blk * n * kGmapDoubles * sizeof(double) : 0));
     L.total = p;
     return L;
@@ -460,7 +481,8 @@ inline void profile_end(hipStream_t st) {
 
 int launch_prep_zyz(int n, const Shape& sh, const double* w, char* ws, const Layout& L, hipStream_t st) {
     hipLaunchKernelGGL(prep_zyz_kernel, dim3((unsigned)(L.zL + 1)), dim3(64), 0, st, sh.runs, n, L.zL, w,
-                       ws + L.off_rec, reinterpret_cast<double*>(ws + L.off_gmap), reinterpret_cast<WorkspaceHeader*>(ws));
+                       ws + L.off_rec, L.zsplit ? ws + L.off_srec : nullptr, reinterpret_cast<double*>(ws + L.off_gmap),
+                       reinterpret_cast<WorkspaceHeader*>(ws));
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 int launch_zyz_forward(int n, const Shape& sh, int64_t B, const Layout& L, char* ws, const AngleSrc& src, double off, double co,
@@ -469,7 +491,12 @@ int launch_zyz_forward(int n, const Shape& sh, int64_t B, const Layout& L, char*
     int nblocks = 0;
     for (int i = 0; i < sh.runs.nruns; ++i) nblocks += sh.runs.count[i];
     const ZFwdArgs za{sh.runs, (long)B, (int)sh.E, ws + L.off_rec, (int)((L.zL + 1) * kRecBytes), L.zL, src, off, co, diag,
-                      pauli, out, state_out, bias, fast, nblocks};
+                      pauli, out, state_out, bias, fast, nblocks, L.zsplit ? ws + L.off_srec : nullptr};
+    if (L.zfwd_split && pauli == QHEA_PAULI_Z) {
+        const dim3 gs((unsigned)((B + kSplitWaves - 1) / kSplitWaves));
+        launch_fwd_split_5(gs, (size_t)kSplitWaves * zyz_cs_row(5, sh.E) * 32, st, za);
+        return QHEA_OK;
+    }
     if (L.zfwd_shared) {
         const long groups = (B + (64 >> n) - 1) / (64 >> n);
         const dim3 gs((unsigned)((groups + kZPWaves - 1) / kZPWaves));
@@ -500,7 +527,8 @@ int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char
     for (int i = 0; i < sh.runs.nruns; ++i) nblocks += sh.runs.count[i];
     const ZBwdArgs za{sh.runs, (long)B, (int)sh.E, (int)sh.blk, ws + L.off_rec, (int)((L.zL + 1) * kRecBytes), L.zL, src, off, co,
                       diag, pauli, g, state_in, y, bias, inv_bt, out, grad_x, partial,
-                      &reinterpret_cast<WorkspaceHeader*>(ws)->status, fast, nblocks};
+                      &reinterpret_cast<WorkspaceHeader*>(ws)->status, fast, nblocks,
+                      (L.zsplit && !L.zpacked) ? ws + L.off_srec : nullptr};
     const size_t dyn = (size_t)(64 >> n) * zyz_cs_row(n, sh.E) * sizeof(double2);
     if (L.zpacked) {
         switch (n) {
@@ -512,7 +540,7 @@ int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char
         return QHEA_OK;
     }
     switch (n) {
-#define QHEA_CASE(NN) case NN: launch_bwd_ztri_##NN(dim3((unsigned)L.nwaves), dyn, st, za); break;
+#define QHEA_CASE(NN) case NN: launch_bwd_ztri_##NN(dim3((unsigned)L.nwaves), za.srec ? 2 * dyn : dyn, st, za); break;
         QHEA_FOR_EACH_ZN(QHEA_CASE)
 #undef QHEA_CASE
         default: return QHEA_EUNSUPPORTED;

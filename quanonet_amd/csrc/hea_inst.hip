@@ -57,11 +57,19 @@ void QHEA_CAT(launch_fwd_zshared_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_
 void QHEA_CAT(launch_bwd_zpacked_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a) {
     hipLaunchKernelGGL(bwd_zpacked_kernel<QHEA_N>, grid, dim3(kZPWaves * 64), dyn_lds, st, a);
 }
+#if QHEA_N == 5
+void launch_fwd_split_5(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArgs& a) {
+    hipLaunchKernelGGL(fwd_split_kernel<5>, grid, dim3((kSplitWaves + kSplitHelpers) * 64), dyn_lds, st, a);
+}
+#endif
 #elif QHEA_N <= 5      // layout-experiment build: the ZYZ kernels need the all-lane layout and are never selected
 void QHEA_CAT(launch_fwd_zyz_, QHEA_N)(dim3, size_t, hipStream_t, const ZFwdArgs&) {}
 void QHEA_CAT(launch_bwd_ztri_, QHEA_N)(dim3, size_t, hipStream_t, const ZBwdArgs&) {}
 void QHEA_CAT(launch_bwd_zpacked_, QHEA_N)(dim3, size_t, hipStream_t, const ZBwdArgs&) {}
 void QHEA_CAT(launch_fwd_zshared_, QHEA_N)(dim3, size_t, hipStream_t, const ZFwdArgs&) {}
+#if QHEA_N == 5
+void launch_fwd_split_5(dim3, size_t, hipStream_t, const ZFwdArgs&) {}
+#endif
 #endif
 
 }  // namespace qhea

@@ -134,6 +134,23 @@ __device__ __forceinline__ void dma_record(const u32x4& rsrc, unsigned lds_addr,
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
+// NREC consecutive records at once: the instruction offset advances the global AND the LDS address, so one M0 serves all
+template <int NREC>
+__device__ __forceinline__ void dma_records(const u32x4& rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    static_assert(NREC >= 1 && NREC <= 3 && kRecBytes == 1024, "instruction offsets are 12 bits");
+    if constexpr (NREC == 1)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+    else if constexpr (NREC == 2)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds"
+                     :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds"
+                     :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
 template <int CNT>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CNT) : "memory"); }
 
@@ -297,8 +314,7 @@ struct BlockStream {
     __device__ __forceinline__ void issue(int b) const {             // b in [-(kBDist+1), nblocks + kBDist + 1]
         const unsigned slot = lds0 + (unsigned)(b & (kBSlots - 1)) * (RPB * kRecBytes);
         const unsigned soff = (unsigned)((b * RPB + kPadRecs) * kRecBytes);
-#pragma unroll
-        for (int i = 0; i < RPB; ++i) dma_record(rsrc, slot + i * kRecBytes, lane16, soff + i * kRecBytes);
+        dma_records<RPB>(rsrc, slot, lane16, soff);
     }
     __device__ __forceinline__ const char* slot(int b) const { return ring + (b & (kBSlots - 1)) * (RPB * kRecBytes); }
     // Per block: landed<D>() at the top (blocks b+D .. b+kBDist*D are in flight, b+D must have landed), ahead<D>(b)
@@ -401,16 +417,165 @@ __device__ __forceinline__ void zyz_forward_fast(double (&re)[1], double (&im)[1
     apply_phase<false>(re[0], im[0], bs.dg[0]);        // record L = record 0 of the slot after the last block
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Split layout, n = 5, forward sweeps of the block-unrolled shapes.  A lone wave's time is its instruction count, and
+// in the all-lane layout every gate is paid twice, once for the real and once for the imaginary part of the wave's
+// two samples.  An RY gate has REAL coefficients: it acts on the real parts and on the imaginary parts separately.
+// So a wave may carry ONE sample with lane = k + 32 p  (k: basis index, p = 0: Re, 1: Im), one double per lane:
+//   RY on qubit q < 4   partner through DPP, x' = c x -/+ s x_partner           2 moves + 2 fp64 (was 4 + 4)
+//   RY on qubit 4       A = B = x; v_permlane16_swap(A, B) leaves the pair's bit-0 value in A and its bit-1 value in
+//                       B for both lanes: x' = u.x A + u.y B, u = (c, -s) / (s, c)    1 copy + 2 swaps + 2 fp64
+//   diagonal e^{i Phi}  the same through v_permlane32_swap (A = Re, B = Im): x' = alpha A + beta B with
+//                       (alpha, beta) = (cos, -sin) for the Re lanes, (sin, cos) for the Im lanes
+//   ring                one gathered double instead of two
+// and EVERY encoding gate runs as RX = RZ(-pi/2) RY RZ(pi/2) with the fixed phases folded into the neighbouring
+// diagonals (the all-lane kernels do that for wire 4 only).  ~30 vector instructions per layer instead of ~50, for
+// half the samples per wave: that pays where waves are lone anyway -- the forward kernel at small batches, and the
+// forward phase of the pipelined backward kernel, where the lambda wave would otherwise idle: psi and lambda wave
+// sweep one sample each, leave psi_N in LDS in the all-lane layout, and the reverse phase runs unchanged.
+//
+// Split records (prep_zyz_kernel), 1 KB per layer like the all-lane ones:
+//   bytes [0, 768)        per basis index k: [-sin, cos, sin] of Phi_l(k); lane (k, p) reads the 16 bytes at 24 k + 8 p
+//                         as (beta, alpha)
+//   bytes [768, 928)      ansatz layers: per wire 32 bytes, the lane-bit 0 / 1 variants (c, -s) / (c, +s); wire 4: (c, -s) / (s, c)
+// (cos, sin) table of the encodings: 32 bytes per angle, wire = column % 5:
+//   wires 0..3 [c, -s | c, +s]   (the second half is what the all-lane reverse walk's native RX wants)
+//   wire 4     [s, c | c, -s]    (split: lane-bit 1 / 0 variants; all-lane reverse walk: (s, c), fields swapped)
+// ---------------------------------------------------------------------------------------
+constexpr int kSRecRy = 768;
+__host__ __device__ inline bool zsplit_eligible(int n, long E, const Runs& r) {
+    return n == 5 && zyz_fast_ld(r, n) != 0 && 2 * zyz_cs_row(n, E) * 32 <= kZCsBytes;
+}
+__device__ __forceinline__ void fill_cs_split(double4* cs, const AngleSrc& src, int E, long b0, long B, int ns, int tid, int nthreads) {
+    const int row = (int)zyz_cs_row(5, E);
+    for (int s = 0; s < ns; ++s) {
+        const long b = (b0 + s < B) ? b0 + s : B - 1;
+        for (int e = tid; e < E; e += nthreads) {
+            double sn, cn;
+            sincos(0.5 * enc_angle(src, E, b, e), &sn, &cn);
+            cs[s * row + 5 + e] = (e % 5 == 4) ? make_double4(sn, cn, cn, -sn) : make_double4(cn, -sn, cn, sn);
+        }
+    }
+}
+// what the all-lane gates (apply_enc) want from a 32-byte entry: (cos, sin)
+template <int Q>
+__device__ __forceinline__ double2 cs32_packed(const double2* chunk /* entry of wire 0 */) {
+    if constexpr (Q == 4) { const double2 t = chunk[2 * Q]; return make_double2(t.y, t.x); }
+    else return chunk[2 * Q + 1];
+}
+
+template <bool HALVES>      // A, B <- the value of the lower / upper partner (rows of 16 lanes, or the wave's halves)
+__device__ __forceinline__ void swap_dup(double x, double& A, double& B) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    if constexpr (HALVES) {
+        const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        A = __hiloint2double((int)h[0], (int)l[0]); B = __hiloint2double((int)h[1], (int)l[1]);
+    } else {
+        const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        A = __hiloint2double((int)h[0], (int)l[0]); B = __hiloint2double((int)h[1], (int)l[1]);
+    }
+}
+__device__ __forceinline__ void split_phase(double& x, const double2& d /* (beta, alpha) */) {
+    double A, B;
+    swap_dup<true>(x, A, B);
+    x = d.y * A + d.x * B;
+}
+template <int Q>
+__device__ __forceinline__ void split_ry(double& x, const double2& u) {
+    if constexpr (Q == 4) {
+        double A, B;
+        swap_dup<false>(x, A, B);
+        x = u.x * A + u.y * B;
+    } else {
+        x = u.x * x + u.y * xchg<(1 << Q)>(x);
+    }
+}
+
+template <int LD>
+struct SplitStream : BlockStream<5, LD, false> {
+    using Base = BlockStream<5, LD, false>;
+    static constexpr int RPB = 1 + LD;
+    unsigned a_cs[5];           // this lane's variant within a 32-byte (cos, sin) entry, + 32 * wire
+    __device__ __forceinline__ void init_split(const char* srec0, int nrec, char* ring_wave, int lane) {
+        Base::init(srec0, nrec, ring_wave, lane, lane & 31);
+        this->a_dg = (unsigned)(lane & 31) * 24u + (unsigned)(lane >> 5) * 8u;
+        static_for<0, 5>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            const unsigned bit = ((unsigned)lane >> Q) & 1u;
+            this->a_ry[Q] = kSRecRy + Q * 32 + bit * 16u;
+            a_cs[Q] = Q * 32 + (Q == 4 ? (1u - bit) : bit) * 16u;
+        });
+    }
+    static __device__ __forceinline__ double2 rd8(const char* p, unsigned off) {       // 8-byte aligned pair
+        const double* q = reinterpret_cast<const double*>(p + off);
+        return make_double2(q[0], q[1]);
+    }
+    __device__ __forceinline__ void load_records_split(const char* sl) {
+#pragma unroll
+        for (int i = 0; i < RPB; ++i) this->dg[i] = rd8(sl, i * kRecBytes + this->a_dg);
+#pragma unroll
+        for (int s = 0; s < LD; ++s)
+            static_for<0, 5>([&](auto q) { this->ry[s][decltype(q)::value] = Base::rd(sl, (1 + s) * kRecBytes + this->a_ry[decltype(q)::value]); });
+    }
+    __device__ __forceinline__ void load_cs_split(const char* chunk) {
+        static_for<0, 5>([&](auto q) { this->cs[decltype(q)::value] = Base::rd(chunk, a_cs[decltype(q)::value]); });
+    }
+};
+
+// forward sweep of ONE sample in the split layout; csrow: the sample's table row, entry of column 0; returns this
+// lane's Re (lanes 0..31) or Im (lanes 32..63) of psi_N[lane & 31]
+template <int LD>
+__device__ __forceinline__ double zsplit_forward(SplitStream<LD>& bs, const char* csrow, int nblocks, int lane, int ring_fwd) {
+    double x = lane == 0 ? 1.0 : 0.0;
+    bs.template prime<1>(0, false);
+    bs.load_records_split(bs.slot(0));
+    bs.load_cs_split(csrow);
+    for (int b = 0; b < nblocks; ++b) {
+        bs.landed();
+        const char* nx = bs.slot(b + 1);
+        split_phase(x, bs.dg[0]);
+        bs.dg[0] = bs.rd8(nx, bs.a_dg);
+        const char* cn = csrow + (b + 1) * (5 * 32);
+        static_for<0, 5>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            split_ry<Q>(x, bs.cs[Q]);
+            bs.cs[Q] = bs.rd(cn, bs.a_cs[Q]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int s = 0; s < LD; ++s) {
+            split_phase(x, bs.dg[1 + s]);
+            bs.dg[1 + s] = bs.rd8(nx, (1 + s) * kRecBytes + bs.a_dg);
+            static_for<0, 5>([&](auto q) {
+                constexpr int Q = decltype(q)::value;
+                split_ry<Q>(x, bs.ry[s][Q]);
+                bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            x = lane_gather(x, ring_fwd);
+            if (s == 0) bs.template ahead<1>(b);          // in the gather's shadow
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    split_phase(x, bs.dg[0]);                            // record L = record 0 of the slot after the last block
+    return x;
+}
+
 struct ZFwdArgs {
     Runs runs; long B; int E; const char* rec; int rec_bytes; int L; AngleSrc src; double off, co;
     const double* diag; int pauli; double* out; double* state_out; const double* bias;
     int fast_ld, nblocks;       // block-unrolled fast path: sub-layers per block (0 = generic walk), number of blocks
+    const char* srec;           // split records (record 0), nullptr: shape not eligible (zsplit_eligible)
 };
 struct ZBwdArgs {
     Runs runs; long B; int E; int blk; const char* rec; int rec_bytes; int L; AngleSrc src; double off, co;
     const double* diag; int pauli; const double* g; const double* state_in; const double* y; const double* bias;
     double inv_bt; double* out; double* grad_x; double* partial; int* status;
     int fast_ld, nblocks;
+    const char* srec;           // split records for the forward phase, nullptr: all-lane forward sweep
 };
 
 // kWaves sweeping waves + kFwdHelpers waves that only help to fill the (cos, sin) tables and then leave: the fill is
@@ -466,6 +631,41 @@ __global__ __launch_bounds__((kWaves + kFwdHelpers) * 64) void fwd_zyz_kernel(ZF
     if (valid && klow == 0) a.out[b] = v[0] + (a.bias ? a.bias[0] : 0.0);
 }
 
+// Forward kernel in the split layout (n = 5, block-unrolled shapes, Z / diagonal read-out): one sample per sweeping
+// wave, kSplitWaves of them per workgroup + helpers for the table fill.  For batches that leave SIMDs free.
+constexpr int kSplitWaves = 2, kSplitHelpers = 2;
+template <int N>
+__global__ __launch_bounds__((kSplitWaves + kSplitHelpers) * 64) void fwd_split_kernel(ZFwdArgs a) {
+    static_assert(N == 5, "split layout: n = 5");
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // kSplitWaves x row x 32 bytes
+    __shared__ __attribute__((aligned(16))) char rec_ring[kSplitWaves * kBlockRingBytes];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long b0 = (long)blockIdx.x * kSplitWaves;
+    fill_cs_split(reinterpret_cast<double4*>(dyn_lds), a.src, a.E, b0, a.B, kSplitWaves, (int)threadIdx.x,
+                  (kSplitWaves + kSplitHelpers) * 64);
+    __syncthreads();
+    const long b = b0 + wib;
+    if (wib >= kSplitWaves || b >= a.B) return;
+    const int k = lane & 31, p = lane >> 5;
+    const int ring_fwd = ring_source<5>(lane, false);
+    const char* row = dyn_lds + (wib * (int)zyz_cs_row(5, a.E) + 5) * 32;
+    double x;
+    if (a.fast_ld == 2) {
+        SplitStream<2> ss;
+        ss.init_split(a.srec, a.L + 1, rec_ring + wib * kBlockRingBytes, lane);
+        x = zsplit_forward<2>(ss, row, a.nblocks, lane, ring_fwd);
+    } else {
+        SplitStream<1> ss;
+        ss.init_split(a.srec, a.L + 1, rec_ring + wib * kBlockRingBytes, lane);
+        x = zsplit_forward<1>(ss, row, a.nblocks, lane, ring_fwd);
+    }
+    if (a.state_out) a.state_out[(((b << 5) + k) << 1) | p] = x;
+    double v[1] = {ham_weight<5>(k, a.off, a.co, a.diag) * (x * x)};
+    lane_reduce<1, 6>(v, lane);
+    if (lane == 0) a.out[b] = v[0] + (a.bias ? a.bias[0] : 0.0);
+}
+
 // ---------------------------------------------------------------------------------------
 // psi / lambda / sigma pipelined backward kernel, ZYZ form.  Roles, rings, counters and failure reporting as in
 // bwd_tri_kernel (hea_device.hpp); a "step" is one layer (one ansatz sub-layer or one RX chunk).
@@ -473,16 +673,20 @@ __global__ __launch_bounds__((kWaves + kFwdHelpers) * 64) void fwd_zyz_kernel(ZF
 // One chain wave of the pipelined backward kernel: role 0 = psi (forward sweep or state_in, then psi walked back),
 // role 1 = lambda (lambda_N = g H psi_N, walked back).  MODE 0: generic layer walk; 1 / 2: block-unrolled fast path
 // with that many sub-layers per block.  Publishing protocol as in bwd_tri_kernel (hea_device.hpp).
-template <int N, int MODE>
+// SPLIT (n = 5, MODE != 0): the (cos, sin) table has the 32-byte entries of the split layout, and the forward phase is
+// swept in that layout by BOTH chain waves, one sample each (zsplit_forward).
+template <int N, int MODE, bool SPLIT>
 __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane, int klow, bool valid, long b,
                                            const double2* cs, char* my_ring, double2 (*psi_ring)[64],
                                            double2 (*lam_ring)[64], double2* psi_final, ZSync* sync) {
     using C = Cfg<N>;
+    static_assert(!SPLIT || (N == 5 && MODE != 0), "split layout: n = 5, block-unrolled shapes");
     __builtin_amdgcn_s_setprio(3);                          // the chains are the critical path (hea_device.hpp)
     const int E = a.E;
     const int ring_fwd = ring_source<N>(lane, false);
     const int ring_rev = ring_source<N>(lane, true);
-    const double2* csrow = cs + (lane >> C::LB) * (int)zyz_cs_row(N, E) + N;
+    // all-lane walks: this lane's sample row; SPLIT: two double2 per column
+    const double2* csrow = cs + ((lane >> C::LB) * (int)zyz_cs_row(N, E) + N) * (SPLIT ? 2 : 1);
     LayerStream<N> ls;
     BlockStream<N, MODE == 0 ? 1 : MODE> bs;
     if constexpr (MODE == 0) ls.init(a.rec, a.rec_bytes, my_ring, lane, klow, a.L);
@@ -491,19 +695,38 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
     int seen[kZSigma];
 #pragma unroll
     for (int w = 0; w < kZSigma; ++w) seen[w] = 0;
-    if (role == 0) {
-        if (a.state_in) {
-            const double2 s0 = reinterpret_cast<const double2*>(a.state_in)[(b << N) + klow];
-            sr[0] = s0.x; si[0] = s0.y;
-        } else {
-            if constexpr (MODE == 0) zyz_forward<N>(sr, si, a.runs, ls, csrow, E, lane, klow, ring_fwd);
-            else zyz_forward_fast<N, MODE>(sr, si, a.runs, bs, csrow, E, lane, klow, ring_fwd);
+    bool swept = false;                                     // psi_N already in psi_final, `ready` counted up by both chains
+    if constexpr (SPLIT) {
+        if (!a.state_in) {
+            SplitStream<MODE> ss;
+            ss.init_split(a.srec, a.L + 1, my_ring, lane);
+            const char* row = reinterpret_cast<const char*>(cs) + (role * (int)zyz_cs_row(5, E) + 5) * 32;
+            const double x = zsplit_forward<MODE>(ss, row, a.nblocks, lane, ring_fwd);
+            reinterpret_cast<double*>(psi_final)[(((role << 5) | (lane & 31)) << 1) | (lane >> 5)] = x;   // all-lane layout
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (lane == 0) __hip_atomic_fetch_add(&sync->ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            swept = true;
         }
-        psi_final[lane] = make_double2(sr[0], si[0]);
-        __hip_atomic_store(&sync->ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (role == 0) {
+        if (swept) {
+            int seen_ready = 0;
+            pair_wait_ge(&sync->ready, 2, &sync->abort, seen_ready);
+            sr[0] = psi_final[lane].x; si[0] = psi_final[lane].y;
+        } else {
+            if (a.state_in) {
+                const double2 s0 = reinterpret_cast<const double2*>(a.state_in)[(b << N) + klow];
+                sr[0] = s0.x; si[0] = s0.y;
+            } else {
+                if constexpr (MODE == 0) zyz_forward<N>(sr, si, a.runs, ls, csrow, E, lane, klow, ring_fwd);
+                else if constexpr (!SPLIT) zyz_forward_fast<N, MODE>(sr, si, a.runs, bs, csrow, E, lane, klow, ring_fwd);
+            }
+            psi_final[lane] = make_double2(sr[0], si[0]);
+            __hip_atomic_store(&sync->ready, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     } else {
         int seen_ready = 0;
-        pair_wait_ge(&sync->ready, 1, &sync->abort, seen_ready);
+        pair_wait_ge(&sync->ready, 2, &sync->abort, seen_ready);
         double fr[1] = {psi_final[lane].x}, fi[1] = {psi_final[lane].y};
         basis_change<N, false>(fr, fi, a.pauli, lane);
         const double h = ham_weight<N>(klow, a.off, a.co, a.diag);
@@ -543,7 +766,11 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
         bs.template step<-1>(nb);                             // block nb-1 landed
         bs.load_records(bs.slot(nb - 1));
         int bl = nb - 1, col = E;
-        bs.load_cs(csrow, col - N);
+        auto load_chunk = [&](int c0) {                       // the RX chunk of columns [c0, c0 + N)
+            if constexpr (SPLIT) static_for<0, N>([&](auto q) { bs.cs[decltype(q)::value] = cs32_packed<decltype(q)::value>(csrow + 2 * c0); });
+            else bs.load_cs(csrow, c0);
+        };
+        load_chunk(col - N);
         for (int ri = a.runs.nruns - 1; ri >= 0; --ri) {
             const int m = a.runs.enc[ri];
             for (int rep = 0; rep < a.runs.count[ri]; ++rep) {
@@ -571,11 +798,12 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
                 bs.dg[1] = bs.rd(nx, kRecBytes + bs.a_dg);
                 publish();
                 col -= m;
-                const double2* cn = csrow + (col - N);        // every block has enc = n: the previous block's chunk
+                const double2* cn = csrow + (col - N) * (SPLIT ? 2 : 1);   // every block has enc = n: the previous block's chunk
                 static_rfor<0, N>([&](auto q) {
                     constexpr int Q = decltype(q)::value;
                     apply_enc<N, Q, true>(sr, si, bs.cs[Q]);
-                    bs.cs[Q] = cn[Q];
+                    if constexpr (SPLIT) bs.cs[Q] = cs32_packed<Q>(cn);
+                    else bs.cs[Q] = cn[Q];
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 apply_phase<true>(sr[0], si[0], bs.dg[0]);    // the diagonal in front of this block's RX chunk: every
@@ -668,15 +896,28 @@ __global__ __launch_bounds__(128 + 64 * kZSigma) void bwd_ztri_kernel(ZBwdArgs a
         for (int w = 0; w < kZSigma; ++w) sync.cursor[w] = w;
     }
     double2* cs = reinterpret_cast<double2*>(dyn_lds);
-    fill_cs(cs, a.src, N, E, wave * C::SPW, a.B, C::SPW, (int)threadIdx.x, 128 + 64 * kZSigma);   // all waves
+    const bool split = N == 5 && a.srec != nullptr && a.fast_ld != 0;
+    if constexpr (N == 5) {
+        if (split) fill_cs_split(reinterpret_cast<double4*>(dyn_lds), a.src, E, wave * C::SPW, a.B, C::SPW, (int)threadIdx.x, 128 + 64 * kZSigma);
+    }
+    if (!split) fill_cs(cs, a.src, N, E, wave * C::SPW, a.B, C::SPW, (int)threadIdx.x, 128 + 64 * kZSigma);   // all waves
     __syncthreads();
 
     if (role < 2) {
         // ------------------------------------------------------------------ psi / lambda chains
         char* my_ring = rec_ring + role * kBlockRingBytes;
-        if (a.fast_ld == 2) ztri_chain<N, 2>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
-        else if (a.fast_ld == 1) ztri_chain<N, 1>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
-        else ztri_chain<N, 0>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+        bool done = false;
+        if constexpr (N == 5) {
+            if (split) {
+                if (a.fast_ld == 2) ztri_chain<N, 2, true>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+                else ztri_chain<N, 1, true>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+                done = true;
+            }
+        }
+        if (done) {}
+        else if (a.fast_ld == 2) ztri_chain<N, 2, false>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+        else if (a.fast_ld == 1) ztri_chain<N, 1, false>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+        else ztri_chain<N, 0, false>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
     } else {
         // ------------------------------------------------------------------ sigma waves: inner products + sums
         double* __restrict__ part_w = a.partial + wave * (long)a.blk * C::KW;
@@ -968,6 +1209,7 @@ __global__ __launch_bounds__(kZPWaves * 64) void fwd_zshared_kernel(ZFwdArgs a) 
     void launch_bwd_ztri_##NN(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a);   \
     void launch_bwd_zpacked_##NN(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a);
 QHEA_FOR_EACH_ZN(QHEA_ZDECLARE)
+void launch_fwd_split_5(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArgs& a);
 #undef QHEA_ZDECLARE
 
 }  // namespace qhea

@@ -74,7 +74,7 @@ def build_roofline(train_kernel_ms, fwd_kernel_ms, pmc, timing_source, batch=BAT
     tf = fwd_kernel_ms * 1e-3 if fwd_kernel_ms else None
     kname, kc = (None, None)
     if pmc:
-        for hint in ('bwd_tri_kernel<5>', 'bwd_pair_kernel<5>', 'bwd_kernel<5', train_kernel_hint):
+        for hint in ('bwd_ztri_kernel<5>', 'bwd_tri_kernel<5>', 'bwd_pair_kernel<5>', 'bwd_kernel<5', train_kernel_hint):
             kname, kc = _pick(pmc, hint)
             if kc:
                 break
@@ -136,9 +136,14 @@ def build_roofline(train_kernel_ms, fwd_kernel_ms, pmc, timing_source, batch=BAT
 
 
 def newest_tag():
-    tags = sorted(m.group(1) for m in (re.match(r'(r\d+[a-z]*)_pmc\.json$', os.path.basename(p))
-                                       for p in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json'))) if m)
-    return tags[-1] if tags else None
+    """Newest set under profiles/: highest round; within a round the plain `rNN` set is the final one, suffixed sets
+    (`rNNa` ...) are earlier snapshots of that round."""
+    tags = [m.groups() for m in (re.match(r'r(\d+)([a-z]*)_pmc\.json$', os.path.basename(p))
+                                 for p in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json'))) if m]
+    if not tags:
+        return None
+    num, suffix = max(tags, key=lambda t: (int(t[0]), t[1] == '', t[1]))
+    return f'r{num}{suffix}'
 
 
 def load_pmc(tag=None):

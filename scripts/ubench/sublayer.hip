@@ -22,6 +22,9 @@ __device__ __forceinline__ double gather(double v, int a) {
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(a, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(a, __double2loint(v)));
 }
 
+#define NEWGATE(M, G) { const double4 u = row[(G) * 2 + ((lane >> (G)) & 1)]; const double qr = xd<M>(re), qi = xd<M>(im); \
+    re = u.x * re - u.y * qr; im = u.x * im - u.y * qi; }
+
 template <int MODE>
 __global__ __launch_bounds__(128) void k(double* out, unsigned long long* cyc, int iters) {
     __shared__ double4 tab[2][2 * 64 * 6];
@@ -30,6 +33,9 @@ __global__ __launch_bounds__(128) void k(double* out, unsigned long long* cyc, i
     double re = 1.0 / 8 + lane * 1e-3, im = 0.01 * lane;
     const int ring = ((lane & 32) | ((lane * 5 + 3) & 31)) << 2;
     const double4* t = tab[w];
+    double4 cf[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) cf[g] = t[g * 2 + (lane & 1)];
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         const double4* row = t + (it & 1) * 64 * 6;
@@ -38,13 +44,72 @@ __global__ __launch_bounds__(128) void k(double* out, unsigned long long* cyc, i
             const double qr = xd<M>(re), qi = xd<M>(im); \
             const double nr = u.x * re - u.y * im + v.x * qr - v.y * qi; const double ni = u.x * im + u.y * re + v.x * qi + v.y * qr; re = nr; im = ni; }
             OLDGATE(1, 0) OLDGATE(2, 1) OLDGATE(4, 2) OLDGATE(8, 3) OLDGATE(16, 4)
+        } else if constexpr (MODE == 2) {
+            // the kernels' current form: wire 4 through v_permlane16_swap (re <-> im rows), no LDS latency on the chain
+            { const double4 d = row[5 * 4 + (lane & 31)]; const double nr = d.x * re - d.y * im, ni = d.x * im + d.y * re; re = nr; im = ni; }
+            NEWGATE(1, 0) NEWGATE(2, 1) NEWGATE(4, 2) NEWGATE(8, 3)
+            { const double4 u = row[4 * 2];
+              auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(re), (unsigned)__double2loint(im), false, false);
+              auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(re), (unsigned)__double2hiint(im), false, false);
+              const double a = __hiloint2double((int)hi[0], (int)lo[0]), b = __hiloint2double((int)hi[1], (int)lo[1]);
+              const double o1 = u.x * a - u.y * b, o2 = u.y * a + u.x * b;
+              auto l2 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(o1), (unsigned)__double2loint(o2), false, false);
+              auto h2 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(o1), (unsigned)__double2hiint(o2), false, false);
+              re = __hiloint2double((int)h2[0], (int)l2[0]); im = __hiloint2double((int)h2[1], (int)l2[1]); }
+        } else if constexpr (MODE == 4 || MODE == 5) {
+            // modes 2 / 3 with the coefficients read one sub-layer ahead, as the kernels do
+            const double4* nrow = t + ((it + 1) & 1) * 64 * 6;
+            double4 nx[6];
+            if constexpr (MODE == 4) {
+                nx[5] = nrow[5 * 4 + (lane & 31)];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) nx[g] = nrow[g * 2 + ((lane >> g) & 1)];
+                nx[4] = nrow[4 * 2];
+                { const double4 d = cf[5]; const double nr = d.x * re - d.y * im, ni = d.x * im + d.y * re; re = nr; im = ni; }
+#define PFGATE(M, G) { const double4 u = cf[G]; const double qr = xd<M>(re), qi = xd<M>(im); re = u.x * re - u.y * qr; im = u.x * im - u.y * qi; }
+                PFGATE(1, 0) PFGATE(2, 1) PFGATE(4, 2) PFGATE(8, 3)
+                { const double4 u = cf[4];
+                  auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(re), (unsigned)__double2loint(im), false, false);
+                  auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(re), (unsigned)__double2hiint(im), false, false);
+                  const double a = __hiloint2double((int)hi[0], (int)lo[0]), b = __hiloint2double((int)hi[1], (int)lo[1]);
+                  const double o1 = u.x * a - u.y * b, o2 = u.y * a + u.x * b;
+                  auto l2 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(o1), (unsigned)__double2loint(o2), false, false);
+                  auto h2 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(o1), (unsigned)__double2hiint(o2), false, false);
+                  re = __hiloint2double((int)h2[0], (int)l2[0]); im = __hiloint2double((int)h2[1], (int)l2[1]); }
+            } else {
+                nx[5] = nrow[5 * 4 + lane];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) nx[g] = nrow[g * 2 + ((lane >> g) & 1)];
+                nx[4] = nrow[4 * 2 + ((lane >> 4) & 1)];
+#define PFSWAP(BUILTIN, U) { const double4 u = U; \
+                  auto lo = BUILTIN((unsigned)__double2loint(re), (unsigned)__double2loint(re), false, false); \
+                  auto hi = BUILTIN((unsigned)__double2hiint(re), (unsigned)__double2hiint(re), false, false); \
+                  const double a = __hiloint2double((int)hi[0], (int)lo[0]), b = __hiloint2double((int)hi[1], (int)lo[1]); \
+                  re = fma(u.y, b, u.x * a); }
+#define PFSPLIT(M, G) { const double4 u = cf[G]; const double own = u.x * re; const double q = xd<M>(re); re = fma(-u.y, q, own); }
+                PFSWAP(__builtin_amdgcn_permlane32_swap, cf[5])
+                PFSPLIT(1, 0) PFSPLIT(2, 1) PFSPLIT(4, 2) PFSPLIT(8, 3)
+                PFSWAP(__builtin_amdgcn_permlane16_swap, cf[4])
+            }
+#pragma unroll
+            for (int g = 0; g < 6; ++g) cf[g] = nx[g];
+        } else if constexpr (MODE == 3) {
+            // split layout: ONE sample per wave, lanes 0..31 hold the real parts, 32..63 the imaginary parts (`re` only)
+#define SWAPFORM(BUILTIN, IDX) { const double4 u = row[IDX]; \
+              auto lo = BUILTIN((unsigned)__double2loint(re), (unsigned)__double2loint(re), false, false); \
+              auto hi = BUILTIN((unsigned)__double2hiint(re), (unsigned)__double2hiint(re), false, false); \
+              const double a = __hiloint2double((int)hi[0], (int)lo[0]), b = __hiloint2double((int)hi[1], (int)lo[1]); \
+              re = u.x * a + u.y * b; }
+#define SPLITGATE(M, G) { const double4 u = row[(G) * 2 + ((lane >> (G)) & 1)]; const double q = xd<M>(re); re = u.x * re - u.y * q; }
+            SWAPFORM(__builtin_amdgcn_permlane32_swap, 5 * 4 + lane)
+            SPLITGATE(1, 0) SPLITGATE(2, 1) SPLITGATE(4, 2) SPLITGATE(8, 3)
+            SWAPFORM(__builtin_amdgcn_permlane16_swap, 4 * 2 + ((lane >> 4) & 1))
         } else {
             { const double4 d = row[5 * 4 + (lane & 31)]; const double nr = d.x * re - d.y * im, ni = d.x * im + d.y * re; re = nr; im = ni; }
-#define NEWGATE(M, G) { const double4 u = row[(G) * 2 + ((lane >> (G)) & 1)]; const double qr = xd<M>(re), qi = xd<M>(im); \
-            re = u.x * re - u.y * qr; im = u.x * im - u.y * qi; }
             NEWGATE(1, 0) NEWGATE(2, 1) NEWGATE(4, 2) NEWGATE(8, 3) NEWGATE(16, 4)
         }
-        re = gather(re, ring); im = gather(im, ring);
+        re = gather(re, ring);
+        if constexpr (MODE != 3 && MODE != 5) im = gather(im, ring);
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = re + im;
@@ -72,5 +137,9 @@ template <int MODE> int run(const char* name) {
 int main() {
     run<0>("OLD  5 x fused SU(2) + ring");
     run<1>("NEW  diagonal + 5 x RY + ring");
+    run<2>("NOW  the same, wire 4 by permlane16_swap");
+    run<3>("SPLIT re/im in lanes: diagonal + 5 x RY + ring");
+    run<4>("NOW, coefficients read one sub-layer ahead");
+    run<5>("SPLIT, coefficients read one sub-layer ahead");
     return 0;
 }
