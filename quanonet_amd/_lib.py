@@ -28,8 +28,8 @@ class ModelDesc(ctypes.Structure):
 
 
 MODEL_QUANONET, MODEL_HEAQNN = 0, 1
-MIN_LIB_VERSION = 400           # 0.4.0: workspace header + qhea_check_status / qhea_set_backward_variant
-BWD_VARIANTS = {'auto': 0, 'packed': 1, 'pair': 2, 'tri': 3, 'ztri': 4, 'zpacked': 5}
+MIN_LIB_VERSION = 410           # 0.4.1: workspace header, qhea_check_status, qhea_set_backward_variant incl. QHEA_BWD_ZTRI2
+BWD_VARIANTS = {'auto': 0, 'packed': 1, 'pair': 2, 'tri': 3, 'ztri': 4, 'zpacked': 5, 'ztri2': 6}
 PAULI = {'Z': 0, 'X': 1, 'Y': 2}
 
 

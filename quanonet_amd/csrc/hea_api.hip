@@ -366,6 +366,7 @@ struct Layout {
     int zL;                 // their layer count (records 0 .. zL)
     bool zsplit;            // n = 5, block-unrolled shape, table fits: split records exist (forward sweeps in the split layout)
     bool zfwd_split;        // ... and the forward kernel is the split one (batches that leave SIMDs free; Z / diagonal read-out)
+    int zpipes;             // bwd_ztri_kernel: sample groups per workgroup (2 halves the partial rows; hea_zyz.hpp)
 };
 
 // Pipelined backward kernels (n <= 5): several waves per sample group (psi chain, lambda chain, sigma waves), so they
@@ -397,7 +398,7 @@ bool use_pair(int n, int64_t B) {
     if (n > 5 || B <= 0 || n == QHEA_EXP_N) return false;
     const int v = g_bwd_variant.load(std::memory_order_relaxed);
     if (v == QHEA_BWD_PACKED || v == QHEA_BWD_ZPACKED) return false;
-    if (v == QHEA_BWD_PAIR || v == QHEA_BWD_TRI || v == QHEA_BWD_ZTRI) return true;
+    if (v == QHEA_BWD_PAIR || v == QHEA_BWD_TRI || v == QHEA_BWD_ZTRI || v == QHEA_BWD_ZTRI2) return true;
     // measured at n = 5 (us per backward call incl. prep/reduce; packed / pipelined): B = 1024 194 / 155, B = 1536
     // 247 / 181, B = 2048 260 / 273 -- pipelined while the sample groups fill at most 3/4 of the SIMDs
     const int spw = 64 >> lane_bits(n);
@@ -428,7 +429,7 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     // variants stay selectable (qhea_set_backward_variant) and take over for shapes whose (cos, sin) table exceeds LDS
     const int var = g_bwd_variant.load(std::memory_order_relaxed);
     const bool zok = zyz_eligible(n, sh.E) && n != QHEA_EXP_N &&
-                     (var == QHEA_BWD_AUTO || var == QHEA_BWD_ZTRI || var == QHEA_BWD_ZPACKED);
+                     (var == QHEA_BWD_AUTO || var == QHEA_BWD_ZTRI || var == QHEA_BWD_ZTRI2 || var == QHEA_BWD_ZPACKED);
     // Measured at cfg 2's circuit (us per call incl. prep / reduce; first-generation / ZYZ form):
     //   forward   B = 1024 55 / 44,  4096 87 / 89,  16384 236 / 255 with a record ring per wave (22 KB of LDS per wave
     //             cap the waves per CU once the batch could fill them) -> one ring per workgroup beyond one wave per SIMD
@@ -440,7 +441,7 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     // forward: private-ring kernel while the sweeps leave SIMDs free, shared-ring kernel (block-unrolled shapes) beyond;
     // other shapes fall back to the first-generation forward once two waves per SIMD are reached
     L.zfwd_shared = fast && (var == QHEA_BWD_ZPACKED || (var == QHEA_BWD_AUTO && L.nwaves_fwd > (long)simd_count()));
-    L.zfwd = zok && (L.zfwd_shared || var == QHEA_BWD_ZTRI || L.nwaves_fwd <= 2L * simd_count());
+    L.zfwd = zok && (L.zfwd_shared || var == QHEA_BWD_ZTRI || var == QHEA_BWD_ZTRI2 || L.nwaves_fwd <= 2L * simd_count());
     L.ztri = zok && L.pair;
     // batches that fill the SIMDs: the one-wave ZYZ kernel for the block-unrolled shapes (B = 16384 at cfg 2's circuit:
     // see DESIGN.md section 3.5), the first-generation packed kernel otherwise
@@ -451,13 +452,24 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
         L.nwaves = ((B + spw - 1) / spw + kZPWaves - 1) / kZPWaves * kZPWaves;      // one partial row per wave, padding waves write zeros
     }
     L.zL = zok ? zyz_layer_count(sh.runs, n) : 0;
+    L.zsplit = zok && zsplit_eligible(n, sh.E, sh.runs);
+    // QHEA_BWD_ZTRI2: two pipelines per workgroup once two workgroups would share a CU anyway, if both fit its LDS.
+    // Measured at cfg 2, B = 1024: HBM traffic per step 30.5 -> 18.9 MB, circuit kernel 99.3 -> 102.8 us (shallower
+    // hand-off rings to fit, one 8-wave workgroup per CU), reduce kernel unchanged (it is latency-bound) -- so AUTO
+    // keeps one pipeline per workgroup.
+    L.zpipes = 1;
+    if (L.ztri && var == QHEA_BWD_ZTRI2 && L.nwaves > (long)simd_count() / 4) {
+        const size_t cs_bytes = (size_t)(64 >> n) * zyz_cs_row(n, sh.E) * (L.zsplit ? 32 : 16);
+        const size_t lds = 2 * (2 * (size_t)kBlockRingBytes + 2 * (size_t)kZRingDepth<2> * 1024 + 1024 + 64) + 2 * cs_bytes +
+                           (size_t)sh.blk * padded_3n(n) * sizeof(double);
+        if (lds <= 158 * 1024) { L.zpipes = 2; L.nwaves = (L.nwaves + 1) / 2; }      // one partial row per workgroup
+    }
     size_t p = kHeaderBytes;                         // WorkspaceHeader
     L.off_U = p;    p = align_up(p + (size_t)(sh.blk + 2) * n * kGateBytes);
     L.off_cs = p;   p = align_up(p + (size_t)B * sh.E * sizeof(double2));
     L.off_part = p; p = align_up(p + (size_t)L.nwaves * sh.blk * padded_3n(n) * sizeof(double));
     L.off_rec = p;  p = align_up(p + (zok ? (size_t)(L.zL + 1 + 2 * kPadRecs) * kRecBytes : 0));   // padded both sides
     if (zok) L.off_rec += (size_t)kPadRecs * kRecBytes;                                           // -> record 0
-    L.zsplit = zok && zsplit_eligible(n, sh.E, sh.runs);
     // one sample per wave: pays while every sweeping wave still gets a SIMD of its own
     L.zfwd_split = L.zsplit && L.zfwd && !L.zfwd_shared && B <= (int64_t)simd_count();
     L.off_srec = p; p = align_up(p + (L.zsplit ? (size_t)(L.zL + 1 + 2 * kPadRecs) * kRecBytes : 0));
@@ -528,7 +540,7 @@ int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char
     const ZBwdArgs za{sh.runs, (long)B, (int)sh.E, (int)sh.blk, ws + L.off_rec, (int)((L.zL + 1) * kRecBytes), L.zL, src, off, co,
                       diag, pauli, g, state_in, y, bias, inv_bt, out, grad_x, partial,
                       &reinterpret_cast<WorkspaceHeader*>(ws)->status, fast, nblocks,
-                      (L.zsplit && !L.zpacked) ? ws + L.off_srec : nullptr};
+                      (L.zsplit && !L.zpacked) ? ws + L.off_srec : nullptr, L.zpipes};
     const size_t dyn = (size_t)(64 >> n) * zyz_cs_row(n, sh.E) * sizeof(double2);
     if (L.zpacked) {
         switch (n) {
@@ -539,8 +551,10 @@ int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char
         }
         return QHEA_OK;
     }
+    const size_t dyn_tri = (size_t)L.zpipes * (za.srec ? 2 * dyn : dyn) +
+                           (L.zpipes == 2 ? (size_t)sh.blk * padded_3n(n) * sizeof(double) : 0);
     switch (n) {
-#define QHEA_CASE(NN) case NN: launch_bwd_ztri_##NN(dim3((unsigned)L.nwaves), za.srec ? 2 * dyn : dyn, st, za); break;
+#define QHEA_CASE(NN) case NN: launch_bwd_ztri_##NN(dim3((unsigned)L.nwaves), dyn_tri, st, za); break;
         QHEA_FOR_EACH_ZN(QHEA_CASE)
 #undef QHEA_CASE
         default: return QHEA_EUNSUPPORTED;
@@ -799,7 +813,7 @@ using namespace qhea;
 
 extern "C" {
 
-int qhea_version(void) { return 400; }
+int qhea_version(void) { return 410; }
 
 const char* qhea_strerror(int code) {
     switch (code) {
@@ -821,7 +835,7 @@ int qhea_profile_next_circuit_kernel(void* start_event, void* stop_event) {
 }
 
 int qhea_set_backward_variant(int variant) {
-    if (variant < QHEA_BWD_AUTO || variant > QHEA_BWD_ZPACKED) return QHEA_EINVAL;
+    if (variant < QHEA_BWD_AUTO || variant > QHEA_BWD_ZTRI2) return QHEA_EINVAL;
     g_bwd_variant.store(variant, std::memory_order_relaxed);
     return QHEA_OK;
 }

@@ -49,7 +49,8 @@ void QHEA_CAT(launch_fwd_zyz_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st
     hipLaunchKernelGGL(fwd_zyz_kernel<QHEA_N>, grid, dim3((kWaves + kFwdHelpers) * 64), dyn_lds, st, a);
 }
 void QHEA_CAT(launch_bwd_ztri_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a) {
-    hipLaunchKernelGGL(bwd_ztri_kernel<QHEA_N>, grid, dim3(128 + 64 * kZSigma), dyn_lds, st, a);
+    if (a.pipes == 2) hipLaunchKernelGGL((bwd_ztri_kernel<QHEA_N, 2>), grid, dim3(2 * 64 * kZPipeWaves), dyn_lds, st, a);
+    else hipLaunchKernelGGL((bwd_ztri_kernel<QHEA_N, 1>), grid, dim3(64 * kZPipeWaves), dyn_lds, st, a);
 }
 void QHEA_CAT(launch_fwd_zshared_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArgs& a) {
     hipLaunchKernelGGL(fwd_zshared_kernel<QHEA_N>, grid, dim3(kZPWaves * 64), dyn_lds, st, a);

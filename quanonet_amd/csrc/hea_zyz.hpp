@@ -490,7 +490,8 @@ __device__ __forceinline__ void split_ry(double& x, const double2& u) {
         swap_dup<false>(x, A, B);
         x = u.x * A + u.y * B;
     } else {
-        x = u.x * x + u.y * xchg<(1 << Q)>(x);
+        const double own = u.x * x;                 // issued while the exchange is under way: exchange -> fma on the chain
+        x = fma(u.y, xchg<(1 << Q)>(x), own);
     }
 }
 
@@ -576,6 +577,7 @@ struct ZBwdArgs {
     double inv_bt; double* out; double* grad_x; double* partial; int* status;
     int fast_ld, nblocks;
     const char* srec;           // split records for the forward phase, nullptr: all-lane forward sweep
+    int pipes;                  // bwd_ztri_kernel: sample groups per workgroup (1 or 2)
 };
 
 // kWaves sweeping waves + kFwdHelpers waves that only help to fill the (cos, sin) tables and then leave: the fill is
@@ -675,7 +677,7 @@ __global__ __launch_bounds__((kSplitWaves + kSplitHelpers) * 64) void fwd_split_
 // with that many sub-layers per block.  Publishing protocol as in bwd_tri_kernel (hea_device.hpp).
 // SPLIT (n = 5, MODE != 0): the (cos, sin) table has the 32-byte entries of the split layout, and the forward phase is
 // swept in that layout by BOTH chain waves, one sample each (zsplit_forward).
-template <int N, int MODE, bool SPLIT>
+template <int N, int MODE, bool SPLIT, int RING>
 __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane, int klow, bool valid, long b,
                                            const double2* cs, char* my_ring, double2 (*psi_ring)[64],
                                            double2 (*lam_ring)[64], double2* psi_final, ZSync* sync) {
@@ -746,12 +748,12 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
     int* prod = role == 0 ? &sync->psi_prod : &sync->lam_prod;
     int step = 0;
     auto publish = [&]() {
-        if (step >= kPairRing) {
+        if (step >= RING) {
 #pragma unroll
             for (int w = 0; w < kZSigma; ++w)
-                pair_wait_ge(&sync->cursor[w], step - kPairRing + 1, &sync->abort, seen[w]);
+                pair_wait_ge(&sync->cursor[w], step - RING + 1, &sync->abort, seen[w]);
         }
-        ring[step & (kPairRing - 1)][lane] = make_double2(sr[0], si[0]);
+        ring[step & (RING - 1)][lane] = make_double2(sr[0], si[0]);
         ++step;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS executes a wave's instructions in order
         __hip_atomic_store(prod, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -871,36 +873,55 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
     }
 }
 
-template <int N>
-__global__ __launch_bounds__(128 + 64 * kZSigma) void bwd_ztri_kernel(ZBwdArgs a) {
+// PIPES = 2: two such pipelines (two sample groups) per workgroup; their sigma waves add the gradient sums into ONE
+// row held in LDS (two addends per element: the order cannot matter), written out once at the end -- half the
+// partial rows for the reduce kernel to read.  Chosen when two workgroups would share a CU anyway (hea_api.hip).
+constexpr int kZPipeWaves = 2 + kZSigma;
+template <int PIPES> constexpr int kZRingDepth = PIPES == 1 ? kPairRing : 8;      // LDS: 2 x (24 + 16 + 20) KB + the row
+template <int N, int PIPES>
+__global__ __launch_bounds__(64 * kZPipeWaves * PIPES) void bwd_ztri_kernel(ZBwdArgs a) {
     using C = Cfg<N>;
     static_assert(C::R == 1, "all-lane layout");
-    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // SPW x E (cos, sin)
-    __shared__ __attribute__((aligned(16))) char rec_ring[2 * kBlockRingBytes];
-    __shared__ double2 psi_ring[kPairRing][64];
-    __shared__ double2 lam_ring[kPairRing][64];
-    __shared__ double2 psi_final[64];
-    __shared__ ZSync sync;
+    constexpr int RING = kZRingDepth<PIPES>;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // PIPES x SPW x E (cos, sin) [+ the shared row]
+    __shared__ __attribute__((aligned(16))) char rec_ring_all[PIPES][2 * kBlockRingBytes];
+    __shared__ double2 psi_ring_all[PIPES][RING][64];
+    __shared__ double2 lam_ring_all[PIPES][RING][64];
+    __shared__ double2 psi_final_all[PIPES][64];
+    __shared__ ZSync sync_all[PIPES];
 
     const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0: psi, 1: lambda, 2..: sigma
-    const long wave = blockIdx.x;                                                 // one sample group per workgroup
-    const long b_raw = wave * C::SPW + (lane >> C::LB);
-    const bool valid = b_raw < a.B;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pipe = PIPES == 1 ? 0 : wv / kZPipeWaves;
+    const int role = PIPES == 1 ? wv : wv % kZPipeWaves;                           // 0: psi, 1: lambda, 2..: sigma
+    const int tid = (int)threadIdx.x - pipe * (64 * kZPipeWaves);                  // within the pipeline
+    char* rec_ring = rec_ring_all[pipe];
+    double2 (*psi_ring)[64] = psi_ring_all[pipe];
+    double2 (*lam_ring)[64] = lam_ring_all[pipe];
+    double2* psi_final = psi_final_all[pipe];
+    ZSync& sync = sync_all[pipe];
+    const long wave = (long)blockIdx.x * PIPES + pipe;                            // one sample group per pipeline; a group past
+    const long b_raw = wave * C::SPW + (lane >> C::LB);                           // the batch runs on copies of the last sample
+    const bool valid = b_raw < a.B;                                               // with lambda = 0
     const long b = valid ? b_raw : a.B - 1;
     const int klow = lane & (C::LANES - 1);
     const int E = a.E;
 
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         sync.psi_prod = 0; sync.lam_prod = 0; sync.ready = 0; sync.abort = 0;
         for (int w = 0; w < kZSigma; ++w) sync.cursor[w] = w;
     }
-    double2* cs = reinterpret_cast<double2*>(dyn_lds);
     const bool split = N == 5 && a.srec != nullptr && a.fast_ld != 0;
-    if constexpr (N == 5) {
-        if (split) fill_cs_split(reinterpret_cast<double4*>(dyn_lds), a.src, E, wave * C::SPW, a.B, C::SPW, (int)threadIdx.x, 128 + 64 * kZSigma);
+    const int cs_bytes = (int)(C::SPW * zyz_cs_row(N, E) * (split ? 32 : 16));
+    double2* cs = reinterpret_cast<double2*>(dyn_lds + pipe * cs_bytes);
+    double* row_lds = reinterpret_cast<double*>(dyn_lds + PIPES * cs_bytes);       // PIPES = 2: blk x KW sums of both groups
+    if constexpr (PIPES > 1) {
+        for (int i = (int)threadIdx.x; i < a.blk * C::KW; i += 64 * kZPipeWaves * PIPES) row_lds[i] = 0.0;
     }
-    if (!split) fill_cs(cs, a.src, N, E, wave * C::SPW, a.B, C::SPW, (int)threadIdx.x, 128 + 64 * kZSigma);   // all waves
+    if constexpr (N == 5) {
+        if (split) fill_cs_split(reinterpret_cast<double4*>(cs), a.src, E, wave * C::SPW, a.B, C::SPW, tid, 64 * kZPipeWaves);
+    }
+    if (!split) fill_cs(cs, a.src, N, E, wave * C::SPW, a.B, C::SPW, tid, 64 * kZPipeWaves);   // all waves of the pipeline
     __syncthreads();
 
     if (role < 2) {
@@ -909,18 +930,18 @@ __global__ __launch_bounds__(128 + 64 * kZSigma) void bwd_ztri_kernel(ZBwdArgs a
         bool done = false;
         if constexpr (N == 5) {
             if (split) {
-                if (a.fast_ld == 2) ztri_chain<N, 2, true>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
-                else ztri_chain<N, 1, true>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+                if (a.fast_ld == 2) ztri_chain<N, 2, true, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+                else ztri_chain<N, 1, true, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
                 done = true;
             }
         }
         if (done) {}
-        else if (a.fast_ld == 2) ztri_chain<N, 2, false>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
-        else if (a.fast_ld == 1) ztri_chain<N, 1, false>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
-        else ztri_chain<N, 0, false>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+        else if (a.fast_ld == 2) ztri_chain<N, 2, false, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+        else if (a.fast_ld == 1) ztri_chain<N, 1, false, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+        else ztri_chain<N, 0, false, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
     } else {
         // ------------------------------------------------------------------ sigma waves: inner products + sums
-        double* __restrict__ part_w = a.partial + wave * (long)a.blk * C::KW;
+        double* __restrict__ part_w = a.partial + wave * (long)a.blk * C::KW;       // PIPES = 1: this group's row
         const int me = role - 2;
         int seen_p = 0, seen_l = 0;
         int col = E, sub = a.blk, step = 0;
@@ -934,11 +955,11 @@ __global__ __launch_bounds__(128 + 64 * kZSigma) void bwd_ztri_kernel(ZBwdArgs a
                     if (step % kZSigma != me) { ++step; continue; }
                     pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
                     pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
-                    const double2* slot = psi_ring[step & (kPairRing - 1)];
+                    const double2* slot = psi_ring[step & (RING - 1)];
                     const double2 p = slot[lane];
                     double2 qv[N];
                     static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
-                    const double2 lm = lam_ring[step & (kPairRing - 1)][lane];
+                    const double2 lm = lam_ring[step & (RING - 1)][lane];
                     __hip_atomic_store(&sync.cursor[me], step + kZSigma, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ++step;
                     double acc3[C::KW];
@@ -952,17 +973,20 @@ __global__ __launch_bounds__(128 + 64 * kZSigma) void bwd_ztri_kernel(ZBwdArgs a
                         acc3[3 * Q + 2] = sg * (lm.x * p.y - lm.y * p.x);
                     });
                     const int vi = butterfly_sum<C::KW>(acc3, lane);
-                    if (butterfly_owner<C::KW>(lane)) part_w[(long)sub * C::KW + vi] = acc3[0];
+                    if (butterfly_owner<C::KW>(lane)) {
+                        if constexpr (PIPES == 1) part_w[(long)sub * C::KW + vi] = acc3[0];
+                        else __hip_atomic_fetch_add(&row_lds[sub * C::KW + vi], acc3[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
                 for (int ch = nch - 1; ch >= 0; --ch) {
                     const int m = ch == nch - 1 ? m_last : N;
                     if (step % kZSigma != me) { ++step; continue; }
                     pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
                     pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
-                    const double2* slot = psi_ring[step & (kPairRing - 1)];
+                    const double2* slot = psi_ring[step & (RING - 1)];
                     double2 qv[N];
                     static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
-                    const double2 lm = lam_ring[step & (kPairRing - 1)][lane];
+                    const double2 lm = lam_ring[step & (RING - 1)][lane];
                     __hip_atomic_store(&sync.cursor[me], step + kZSigma, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ++step;
                     double gx[C::KX];
@@ -984,6 +1008,11 @@ __global__ __launch_bounds__(128 + 64 * kZSigma) void bwd_ztri_kernel(ZBwdArgs a
         }
     }
     report_abort(&sync.abort, a.status, lane);
+    if constexpr (PIPES > 1) {
+        __syncthreads();                                   // every wave gets here, also after an overrun
+        double* __restrict__ row = a.partial + (long)blockIdx.x * a.blk * C::KW;
+        for (int i = (int)threadIdx.x; i < a.blk * C::KW; i += 64 * kZPipeWaves * PIPES) row[i] = row_lds[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------

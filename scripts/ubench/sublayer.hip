@@ -37,6 +37,7 @@ __global__ __launch_bounds__(128) void k(double* out, unsigned long long* cyc, i
 #pragma unroll
     for (int g = 0; g < 6; ++g) cf[g] = t[g * 2 + (lane & 1)];
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tl = t0, tg0 = 0, tg1 = 0;
     for (int it = 0; it < iters; ++it) {
         const double4* row = t + (it & 1) * 64 * 6;
         if constexpr (MODE == 0) {
@@ -56,11 +57,11 @@ __global__ __launch_bounds__(128) void k(double* out, unsigned long long* cyc, i
               auto l2 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(o1), (unsigned)__double2loint(o2), false, false);
               auto h2 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(o1), (unsigned)__double2hiint(o2), false, false);
               re = __hiloint2double((int)h2[0], (int)l2[0]); im = __hiloint2double((int)h2[1], (int)l2[1]); }
-        } else if constexpr (MODE == 4 || MODE == 5) {
+        } else if constexpr (MODE == 4 || MODE == 5 || MODE == 6 || MODE == 7) {
             // modes 2 / 3 with the coefficients read one sub-layer ahead, as the kernels do
             const double4* nrow = t + ((it + 1) & 1) * 64 * 6;
             double4 nx[6];
-            if constexpr (MODE == 4) {
+            if constexpr (MODE == 4 || MODE == 6) {
                 nx[5] = nrow[5 * 4 + (lane & 31)];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) nx[g] = nrow[g * 2 + ((lane >> g) & 1)];
@@ -108,19 +109,23 @@ __global__ __launch_bounds__(128) void k(double* out, unsigned long long* cyc, i
             { const double4 d = row[5 * 4 + (lane & 31)]; const double nr = d.x * re - d.y * im, ni = d.x * im + d.y * re; re = nr; im = ni; }
             NEWGATE(1, 0) NEWGATE(2, 1) NEWGATE(4, 2) NEWGATE(8, 3) NEWGATE(16, 4)
         }
+        unsigned long long ta = 0;
+        if constexpr (MODE >= 6) { ta = __builtin_amdgcn_s_memtime(); tg0 += ta - tl; }
         re = gather(re, ring);
-        if constexpr (MODE != 3 && MODE != 5) im = gather(im, ring);
+        if constexpr (MODE != 3 && MODE != 5 && MODE != 7) im = gather(im, ring);
+        if constexpr (MODE >= 6) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tl = __builtin_amdgcn_s_memtime(); tg1 += tl - ta; }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = re + im;
     if (lane == 0) cyc[blockIdx.x * 2 + w] = t1 - t0;
+    if constexpr (MODE >= 6) { if (lane == 0 && blockIdx.x == 0 && w == 0) { cyc[2 * gridDim.x] = tg0; cyc[2 * gridDim.x + 1] = tg1; } }
 }
 
 template <int MODE> int run(const char* name) {
     double* out; unsigned long long* cyc;
     const int blocks = 256, iters = 4000;
     CHECK(hipMalloc(&out, sizeof(double) * blocks * 128));
-    CHECK(hipMalloc(&cyc, sizeof(unsigned long long) * blocks * 2));
+    CHECK(hipMalloc(&cyc, sizeof(unsigned long long) * (blocks * 2 + 2)));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(128), 0, 0, out, cyc, iters);
     hipEventRecord(e0);
@@ -128,9 +133,10 @@ template <int MODE> int run(const char* name) {
     hipEventRecord(e1);
     CHECK(hipDeviceSynchronize());
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(blocks * 2);
-    CHECK(hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * blocks * 2, hipMemcpyDeviceToHost));
-    double avg = 0; for (auto v : h) avg += v; avg /= h.size();
+    std::vector<unsigned long long> h(blocks * 2 + 2);
+    CHECK(hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * (blocks * 2 + 2), hipMemcpyDeviceToHost));
+    double avg = 0; for (int i = 0; i < blocks * 2; ++i) avg += h[i]; avg /= blocks * 2;
+    if (MODE >= 6) printf("    gates part %.1f ticks, gather part %.1f ticks per sub-layer (wave 0)\n", (double)h[blocks * 2] / iters, (double)h[blocks * 2 + 1] / iters);
     printf("%-44s %.2f memtime ticks (= %.0f ns) per sub-layer; wall %.1f ns per sub-layer\n", name, avg / iters, 10.0 * avg / iters, ms * 1e6 / iters);
     return 0;
 }
@@ -141,5 +147,7 @@ int main() {
     run<3>("SPLIT re/im in lanes: diagonal + 5 x RY + ring");
     run<4>("NOW, coefficients read one sub-layer ahead");
     run<5>("SPLIT, coefficients read one sub-layer ahead");
+    run<6>("NOW (prefetched), timed segments");
+    run<7>("SPLIT (prefetched), timed segments");
     return 0;
 }

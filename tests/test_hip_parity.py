@@ -165,6 +165,33 @@ def test_uniform_block_shapes(dev, n, ld, backward_variant):
             np.testing.assert_allclose(gw, rgw, rtol=0, atol=TOL, err_msg=msg)
 
 
+@pytest.mark.parametrize('ld', [1, 2])
+def test_two_pipelines_per_workgroup(dev, ld):
+    """'ztri2' at n = 5 batches of more sample groups than CUs: the pipelined backward kernel runs two groups per
+    workgroup and adds their gradient sums in LDS (hea_zyz.hpp, PIPES = 2); an odd group count leaves the last
+    workgroup's second pipeline without samples.  The forward phase sweeps in the split layout."""
+    from quanonet_amd import _lib
+    n = 5
+    rng = np.random.default_rng(5150 + ld)
+    _lib.set_backward_variant('ztri2')
+    try:
+        for cfgs, B in [([(n, ld)] * 4, 2 * 259), ([(n, ld)] * 3, 2 * 258 + 1)]:
+            E, blk = O.circuit_sizes(n, cfgs)
+            x = rng.uniform(-np.pi, np.pi, (B, E))
+            w = rng.uniform(-np.pi, np.pi, (blk, 3, n))
+            g = rng.normal(size=B)
+            off, co = O.ham_params(n, -2.0, 5.0)
+            ro, rgx, rgw = C.hea_backward(n, cfgs, x, w, g, off, co)
+            out, st, gx, gw, out2 = _run(n, cfgs, x, w, g, dev, off, co, use_state=False)
+            np.testing.assert_allclose(out, ro, rtol=0, atol=TOL)
+            np.testing.assert_allclose(out2, ro, rtol=0, atol=TOL)
+            np.testing.assert_allclose(gx, rgx, rtol=0, atol=TOL)
+            np.testing.assert_allclose(gw, rgw, rtol=0, atol=1e-9)      # sums over 500+ samples
+    finally:
+        _lib.set_backward_variant('auto')
+        _lib.check_status(dev)
+
+
 def test_ham_diag_readout(dev):
     n, cfgs = 4, [(4, 1), (4, 2)]
     rng = np.random.default_rng(7)
