@@ -90,6 +90,8 @@ def main():
     ap.add_argument('--backend', default='nccl', help='collective backend; "gloo" + --same-device rehearses N>1 on one GPU')
     ap.add_argument('--same-device', action='store_true', help='rehearsal only: every rank uses cuda:0')
     ap.add_argument('--batch', type=int, default=BATCH, help='samples per GPU and step (the headline is 1024)')
+    ap.add_argument('--backward-variant', default='auto',
+                    help='measurement only: force an n <= 5 kernel variant (quanonet_amd._lib.BWD_VARIANTS); the headline is "auto"')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -121,6 +123,7 @@ def main():
     import roofline_from_profiles as RF
 
     batch = args.batch
+    _lib.set_backward_variant(args.backward_variant)          # before any workspace is sized
     torch.manual_seed(0)
     model = QuanONetPT(N_QUBITS, B_IN, T_IN, NET, scale_coeff=0.1, if_trainable_freq=True).to(dev)
     trainer = DataParallelTrainer(model, lr=1e-4, world_size=world, dist=dist)

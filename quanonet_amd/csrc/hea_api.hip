@@ -649,6 +649,16 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
             const double* __restrict__ in = sg.in + ee % sg.width;
             const double* __restrict__ gx = grad_x + e;
             long b = slice;
+            for (; b + 15L * kFreqSlices < B; b += 16L * kFreqSlices) {    // 32 loads in flight per thread: B = 1024 in ONE round trip
+                double g[16], v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    g[i] = gx[(b + (long)i * kFreqSlices) * E];
+                    v[i] = in[(b + (long)i * kFreqSlices) * sg.width];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s0 += g[i]; s1 += g[i] * v[i]; }
+            }
             for (; b + 7L * kFreqSlices < B; b += 8L * kFreqSlices) {      // 16 loads in flight per thread
                 double g[8], v[8];
 #pragma unroll

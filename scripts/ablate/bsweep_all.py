@@ -20,7 +20,7 @@ def med(fn, reps=15):
 for B in (512, 1024, 2048, 3072, 4096, 8192, 16384):
     x = t(rng.uniform(-3, 3, (B, E))); g = t(rng.normal(size=B))
     res = []
-    for v in ('auto', 'packed', 'zpacked', 'tri', 'ztri'):
+    for v in ('auto', 'packed', 'zpacked', 'tri', 'ztri', 'ztri2'):
         _lib.set_backward_variant(v)
         res.append(f'{v} {med(lambda: _lib.hea_backward(sh, x, w, g, off, co)):.1f}')
     _lib.set_backward_variant('auto'); fa = med(lambda: _lib.hea_forward(sh, x, w, off, co))
