@@ -74,7 +74,7 @@ def build_roofline(train_kernel_ms, fwd_kernel_ms, pmc, timing_source, batch=BAT
     tf = fwd_kernel_ms * 1e-3 if fwd_kernel_ms else None
     kname, kc = (None, None)
     if pmc:
-        for hint in ('bwd_ztri_kernel<5>', 'bwd_tri_kernel<5>', 'bwd_pair_kernel<5>', 'bwd_kernel<5', train_kernel_hint):
+        for hint in ('bwd_ztri_kernel<5', 'bwd_tri_kernel<5>', 'bwd_pair_kernel<5>', 'bwd_kernel<5', train_kernel_hint):
             kname, kc = _pick(pmc, hint)
             if kc:
                 break
@@ -165,7 +165,11 @@ def main():
     stats = os.path.join(ROOT, 'profiles', f'{tag}_bench_kernel_stats.csv')
     rows = {r['Name']: r for r in csv.DictReader(open(stats))}
     k_train, r_train = _pick(rows, 'bwd_', '<5')
-    k_fwd, r_fwd = _pick(rows, 'fwd_kernel<5>')
+    k_fwd, r_fwd = None, None
+    for hint in ('fwd_split_kernel<5', 'fwd_zyz_kernel<5', 'fwd_kernel<5'):
+        k_fwd, r_fwd = _pick(rows, hint)
+        if r_fwd:
+            break
     roof = build_roofline(float(r_train['AverageNs']) * 1e-6, float(r_fwd['AverageNs']) * 1e-6 if r_fwd else None, pmc,
                           f"rocprofv3 --kernel-trace --stats average of {r_train['Calls']} launches ({os.path.basename(stats)})")
     if src:

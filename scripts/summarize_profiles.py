@@ -10,12 +10,14 @@ for nm in ('bench', 'bench_k20'):
         line = [l for l in open(f'{src}/{nm}.json').read().strip().splitlines() if l.startswith('{')][-1]
         json.dump(json.loads(line), open(f'profiles/{tag}_{nm}.json', 'w'), indent=1)
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # gpurun merges runs: take the latest
-stats = newest(f'{src}/trace/*/*_kernel_stats.csv')
-rows = list(csv.DictReader(open(stats)))
-with open(f'profiles/{tag}_bench_kernel_stats.csv', 'w') as f:
-    w = csv.writer(f); w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage'])
-    for r in rows:
-        w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage']])
+rows = []
+if glob.glob(f'{src}/trace/*/*_kernel_stats.csv'):                  # (a counters-only directory has no trace)
+    stats = newest(f'{src}/trace/*/*_kernel_stats.csv')
+    rows = list(csv.DictReader(open(stats)))
+    with open(f'profiles/{tag}_bench_kernel_stats.csv', 'w') as f:
+        w = csv.writer(f); w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage'])
+        for r in rows:
+            w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage']])
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f'{src}/pmc_*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
