@@ -278,6 +278,8 @@ __device__ __forceinline__ void zyz_forward(double (&re)[1], double (&im)[1], co
 // Other shapes take the generic layer walk above.  The record table is padded on both sides (kPadRecs records,
 // never written, never used in arithmetic), so the fetches at the ends need no clamping.
 // ---------------------------------------------------------------------------------------
+template <int K> using CtSlot = std::integral_constant<int, K>;
+struct RtSlot { int b; };
 constexpr int kBSlots = 4, kBDist = 2;         // block slots per ring; blocks in flight beyond the one being read
 constexpr int kPadRecs = 9;                    // >= (kBDist + 1) * 3 records of padding before record 0 and after record L
 constexpr int kBlockRingBytes = kBSlots * 3 * kRecBytes;     // per streaming wave (LD = 2)
@@ -317,6 +319,20 @@ struct BlockStream {
         dma_records<RPB>(rsrc, slot, lane16, soff);
     }
     __device__ __forceinline__ const char* slot(int b) const { return ring + (b & (kBSlots - 1)) * (RPB * kRecBytes); }
+    // The walks are unrolled over the kBSlots ring slots (CtSlot<K>: the block at hand sits in slot K), so that every
+    // ring address is this lane's offset register + an immediate: no slot arithmetic, no address adds per block.  A
+    // walk's first / last few blocks, where the block index is not aligned to the unrolled body, use RtSlot.
+    template <int D, int K>
+    static constexpr int slot_off(CtSlot<K>) { return ((K + D) & (kBSlots - 1)) * (RPB * kRecBytes); }
+    template <int D>
+    static __device__ __forceinline__ int slot_off(RtSlot s) { return ((s.b + D) & (kBSlots - 1)) * (RPB * kRecBytes); }
+    template <int D, class SL>
+    __device__ __forceinline__ const char* slot_rel(SL s) const { return ring + slot_off<D>(s); }
+    template <int D, class SL>
+    __device__ __forceinline__ void ahead_rel(SL s, int b) const {       // fetch block b + D into the slot D ahead of s
+        if (!SHARED || loader)
+            dma_records<RPB>(rsrc, lds0 + (unsigned)slot_off<D>(s), lane16, (unsigned)(((b + D) * RPB + kPadRecs) * kRecBytes));
+    }
     // Per block: landed<D>() at the top (blocks b+D .. b+kBDist*D are in flight, b+D must have landed), ahead<D>(b)
     // later in the block -- in the latency shadow of a ring gather -- fetches block b + (kBDist+1) D.
     __device__ __forceinline__ void landed() const {
@@ -534,12 +550,13 @@ __device__ __forceinline__ double zsplit_forward(SplitStream<LD>& bs, const char
     bs.template prime<1>(0, false);
     bs.load_records_split(bs.slot(0));
     bs.load_cs_split(csrow);
-    for (int b = 0; b < nblocks; ++b) {
+    const char* cs_b = csrow;                            // entry of block b's first column
+    auto block = [&](auto sl, int b, int kb) {           // block b = the unrolled body's block kb (its cs entries: immediates)
         bs.landed();
-        const char* nx = bs.slot(b + 1);
+        const char* nx = bs.template slot_rel<1>(sl);
         split_phase(x, bs.dg[0]);
         bs.dg[0] = bs.rd8(nx, bs.a_dg);
-        const char* cn = csrow + (b + 1) * (5 * 32);
+        const char* cn = cs_b + (kb + 1) * (5 * 32);
         static_for<0, 5>([&](auto q) {
             constexpr int Q = decltype(q)::value;
             split_ry<Q>(x, bs.cs[Q]);
@@ -557,9 +574,21 @@ __device__ __forceinline__ double zsplit_forward(SplitStream<LD>& bs, const char
                 __builtin_amdgcn_sched_barrier(0);
             });
             x = lane_gather(x, ring_fwd);
-            if (s == 0) bs.template ahead<1>(b);          // in the gather's shadow
+            if (s == 0) bs.template ahead_rel<kBDist + 1>(sl, b);      // in the gather's shadow
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    int b = 0;
+    for (; b + kBSlots <= nblocks; b += kBSlots) {       // b is a multiple of kBSlots: block b + K sits in slot K
+        block(CtSlot<0>{}, b, 0);
+        block(CtSlot<1>{}, b + 1, 1);
+        block(CtSlot<2>{}, b + 2, 2);
+        block(CtSlot<3>{}, b + 3, 3);
+        cs_b += kBSlots * (5 * 32);
+    }
+    for (; b < nblocks; ++b) {
+        block(RtSlot{b}, b, 0);
+        cs_b += 5 * 32;
     }
     split_phase(x, bs.dg[0]);                            // record L = record 0 of the slot after the last block
     return x;
@@ -767,51 +796,60 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
         apply_phase<true>(sr[0], si[0], bs.rd(bs.slot(nb), bs.a_dg));     // block nb's slot: its record 0 is the final diagonal
         bs.template step<-1>(nb);                             // block nb-1 landed
         bs.load_records(bs.slot(nb - 1));
-        int bl = nb - 1, col = E;
-        auto load_chunk = [&](int c0) {                       // the RX chunk of columns [c0, c0 + N)
-            if constexpr (SPLIT) static_for<0, N>([&](auto q) { bs.cs[decltype(q)::value] = cs32_packed<decltype(q)::value>(csrow + 2 * c0); });
-            else bs.load_cs(csrow, c0);
+        constexpr int CW = SPLIT ? 2 : 1;                     // double2 per table column
+        auto load_chunk = [&](const double2* chunk) {         // the RX chunk whose first column's entry is `chunk`
+            if constexpr (SPLIT) static_for<0, N>([&](auto q) { bs.cs[decltype(q)::value] = cs32_packed<decltype(q)::value>(chunk); });
+            else static_for<0, N>([&](auto q) { bs.cs[decltype(q)::value] = chunk[decltype(q)::value]; });
         };
-        load_chunk(col - N);
-        for (int ri = a.runs.nruns - 1; ri >= 0; --ri) {
-            const int m = a.runs.enc[ri];
-            for (int rep = 0; rep < a.runs.count[ri]; ++rep) {
-                bs.landed();                                  // block bl-1 landed
-                const char* nx = bs.slot(bl - 1);
+        const double2* cs_b = csrow + (long)(nb - 1) * N * CW;    // chunk of the block at hand (every block has enc = n)
+        load_chunk(cs_b);
+        // one block, sitting in ring slot `sl`; kb: its position in the unrolled body (cs_b stays on the body's first block)
+        auto block = [&](auto sl, int bl, int kb) {
+            bs.landed();                                  // block bl-1 landed
+            const char* nx = bs.template slot_rel<-1>(sl);
 #pragma unroll
-                for (int s = LD - 1; s >= 0; --s) {
-                    if (s != LD - 1) {                        // (the diagonal after the block's last sub-layer was undone
-                        apply_phase<true>(sr[0], si[0], bs.dg[s + 2]);     //  at the end of the previous iteration)
-                        bs.dg[s + 2] = bs.rd(nx, (s + 2) * kRecBytes + bs.a_dg);
-                    }
-                    sr[0] = lane_gather(sr[0], ring_rev);
-                    si[0] = lane_gather(si[0], ring_rev);
-                    if (s == LD - 1) bs.template ahead<-1>(bl);   // in the gather's shadow
-                    __builtin_amdgcn_sched_barrier(0);
-                    publish();
-                    static_rfor<0, N>([&](auto q) {
-                        constexpr int Q = decltype(q)::value;
-                        apply_ry<Q, true>(sr[0], si[0], bs.ry[s][Q]);
-                        bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    });
+            for (int s = LD - 1; s >= 0; --s) {
+                if (s != LD - 1) {                        // (the diagonal after the block's last sub-layer was undone
+                    apply_phase<true>(sr[0], si[0], bs.dg[s + 2]);     //  at the end of the previous block)
+                    bs.dg[s + 2] = bs.rd(nx, (s + 2) * kRecBytes + bs.a_dg);
                 }
-                apply_phase<true>(sr[0], si[0], bs.dg[1]);
-                bs.dg[1] = bs.rd(nx, kRecBytes + bs.a_dg);
+                sr[0] = lane_gather(sr[0], ring_rev);
+                si[0] = lane_gather(si[0], ring_rev);
+                if (s == LD - 1) bs.template ahead_rel<-(kBDist + 1)>(sl, bl);   // in the gather's shadow
+                __builtin_amdgcn_sched_barrier(0);
                 publish();
-                col -= m;
-                const double2* cn = csrow + (col - N) * (SPLIT ? 2 : 1);   // every block has enc = n: the previous block's chunk
                 static_rfor<0, N>([&](auto q) {
                     constexpr int Q = decltype(q)::value;
-                    apply_enc<N, Q, true>(sr, si, bs.cs[Q]);
-                    if constexpr (SPLIT) bs.cs[Q] = cs32_packed<Q>(cn);
-                    else bs.cs[Q] = cn[Q];
+                    apply_ry<Q, true>(sr[0], si[0], bs.ry[s][Q]);
+                    bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                apply_phase<true>(sr[0], si[0], bs.dg[0]);    // the diagonal in front of this block's RX chunk: every
-                bs.dg[0] = bs.rd(nx, bs.a_dg);                // diagonal an iteration undoes is one of its own records
-                --bl;
             }
+            apply_phase<true>(sr[0], si[0], bs.dg[1]);
+            bs.dg[1] = bs.rd(nx, kRecBytes + bs.a_dg);
+            publish();
+            const double2* cn = cs_b - (kb + 1) * (N * CW);   // the previous block's chunk
+            static_rfor<0, N>([&](auto q) {
+                constexpr int Q = decltype(q)::value;
+                apply_enc<N, Q, true>(sr, si, bs.cs[Q]);
+                if constexpr (SPLIT) bs.cs[Q] = cs32_packed<Q>(cn);
+                else bs.cs[Q] = cn[Q];
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            apply_phase<true>(sr[0], si[0], bs.dg[0]);    // the diagonal in front of this block's RX chunk: every
+            bs.dg[0] = bs.rd(nx, bs.a_dg);                // diagonal a block undoes is one of its own records
+        };
+        int bl = nb - 1;
+        for (; bl >= 0 && (bl & (kBSlots - 1)) != kBSlots - 1; --bl) {     // down to a block in the last slot
+            block(RtSlot{bl}, bl, 0);
+            cs_b -= N * CW;
+        }
+        for (; bl >= kBSlots - 1; bl -= kBSlots) {            // bl = 3 (mod 4): block bl - K sits in slot 3 - K
+            block(CtSlot<3>{}, bl, 0);
+            block(CtSlot<2>{}, bl - 1, 1);
+            block(CtSlot<1>{}, bl - 2, 2);
+            block(CtSlot<0>{}, bl - 3, 3);
+            cs_b -= kBSlots * (N * CW);
         }
     } else {
         // ---- generic reverse walk over the layers: [diagonal of record l+1]^-1, ring^-1 (ansatz), publish, [layer l]^-1
