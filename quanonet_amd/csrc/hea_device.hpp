@@ -1140,6 +1140,7 @@ struct PairSync {
 // already far enough) costs no LDS access at all.
 __device__ __forceinline__ bool pair_wait_ge(int* counter, int target, int* abort_flag, int& seen) {
     if (seen >= target) return true;
+#pragma clang loop unroll(disable)              // (the compiler unrolls the spin 8x otherwise: 26 KB of reverse-walk code)
     for (int it = 0; it < kSpinLimit; ++it) {
         seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (seen >= target) return true;

@@ -393,46 +393,54 @@ __device__ __forceinline__ void zyz_forward_fast(double (&re)[1], double (&im)[1
     bs.template prime<1>(0, false);
     bs.load_records(bs.slot(0));
     bs.load_cs(csrow, 0);
-    int b = 0, col = 0;
-    for (int ri = 0; ri < runs.nruns; ++ri) {
-        const int m = runs.enc[ri];
-        for (int rep = 0; rep < runs.count[ri]; ++rep) {
-            // Every coefficient register is refilled with the next block's value right after its last use, and the
-            // scheduler is kept from sinking those LDS reads towards the ring gather (sched_barrier): queued in
-            // front of the gather they would add their service time to its latency, which the chain waits out.
-            bs.landed();
-            const char* nx = bs.slot(b + 1);
-            apply_phase<false>(re[0], im[0], bs.dg[0]);
-            bs.dg[0] = bs.rd(nx, bs.a_dg);
-            col += m;
-            const double2* cn = csrow + col;
+    int nblocks = 0;                                      // every block has enc = n (zyz_fast_ld)
+    for (int ri = 0; ri < runs.nruns; ++ri) nblocks += runs.count[ri];
+    const double2* cs_b = csrow;                          // first column of the unrolled body's first block
+    // Every coefficient register is refilled with the next block's value right after its last use, and the scheduler
+    // is kept from sinking those LDS reads towards the ring gather (sched_barrier): queued in front of the gather they
+    // would add their service time to its latency, which the chain waits out.
+    auto block = [&](auto sl, int b, int kb) {
+        bs.landed();
+        const char* nx = bs.template slot_rel<1>(sl);
+        apply_phase<false>(re[0], im[0], bs.dg[0]);
+        bs.dg[0] = bs.rd(nx, bs.a_dg);
+        const double2* cn = cs_b + (kb + 1) * N;
+        static_for<0, N>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            apply_enc<N, Q, false>(re, im, bs.cs[Q]);
+            bs.cs[Q] = cn[Q];
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int s = 0; s < LD; ++s) {
+            apply_phase<false>(re[0], im[0], bs.dg[1 + s]);
+            bs.dg[1 + s] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_dg);
             static_for<0, N>([&](auto q) {
                 constexpr int Q = decltype(q)::value;
-                apply_enc<N, Q, false>(re, im, bs.cs[Q]);
-                bs.cs[Q] = cn[Q];
+                apply_ry<Q, false>(re[0], im[0], bs.ry[s][Q]);
+                bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
                 __builtin_amdgcn_sched_barrier(0);
             });
-#pragma unroll
-            for (int s = 0; s < LD; ++s) {
-                apply_phase<false>(re[0], im[0], bs.dg[1 + s]);
-                bs.dg[1 + s] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_dg);
-                static_for<0, N>([&](auto q) {
-                    constexpr int Q = decltype(q)::value;
-                    apply_ry<Q, false>(re[0], im[0], bs.ry[s][Q]);
-                    bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                re[0] = lane_gather(re[0], ring_fwd);
-                im[0] = lane_gather(im[0], ring_fwd);
-                if (s == 0) bs.template ahead<1>(b);          // in the gather's shadow
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            ++b;
+            re[0] = lane_gather(re[0], ring_fwd);
+            im[0] = lane_gather(im[0], ring_fwd);
+            if (s == 0) bs.template ahead_rel<kBDist + 1>(sl, b);      // in the gather's shadow
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    int b = 0;
+    for (; b + kBSlots <= nblocks; b += kBSlots) {        // b is a multiple of kBSlots: block b + K sits in slot K
+        block(CtSlot<0>{}, b, 0);
+        block(CtSlot<1>{}, b + 1, 1);
+        block(CtSlot<2>{}, b + 2, 2);
+        block(CtSlot<3>{}, b + 3, 3);
+        cs_b += kBSlots * N;
+    }
+    for (; b < nblocks; ++b) {
+        block(RtSlot{b}, b, 0);
+        cs_b += N;
     }
     apply_phase<false>(re[0], im[0], bs.dg[0]);        // record L = record 0 of the slot after the last block
 }
-
 
 // ---------------------------------------------------------------------------------------
 // Split layout, n = 5, forward sweeps of the block-unrolled shapes.  A lone wave's time is its instruction count, and
@@ -1153,54 +1161,64 @@ __device__ __forceinline__ void zpacked_body(const ZBwdArgs& a, int wib, int lan
     }
     bs.template step<-1>(nb);
     bs.load_records(bs.slot(nb - 1));
-    int bl = nb - 1, col = E, sub = a.blk;
-    bs.load_cs(csrow, col - N);
+    int sub = a.blk;
+    const double2* cs_b = csrow + (long)(nb - 1) * N;             // chunk of the block at hand (every block has enc = n)
+    bs.load_cs(cs_b, 0);
     double* __restrict__ part_w = a.partial + wave * (long)a.blk * C::KW;
-    for (int ri = a.runs.nruns - 1; ri >= 0; --ri) {
-        for (int rep = 0; rep < a.runs.count[ri]; ++rep) {
-            bs.landed();
-            const char* nx = bs.slot(bl - 1);
+    // one block, sitting in ring slot `sl` (walk unrolled over the ring slots like the other block walks)
+    auto block = [&](auto sl, int bl, int kb) {
+        bs.landed();
+        const char* nx = bs.template slot_rel<-1>(sl);
 #pragma unroll
-            for (int s = LD - 1; s >= 0; --s) {
-                if (s != LD - 1) {
-                    apply_phase<true>(pr[0], pi[0], bs.dg[s + 2]);
-                    apply_phase<true>(lr[0], li[0], bs.dg[s + 2]);
-                    bs.dg[s + 2] = bs.rd(nx, (s + 2) * kRecBytes + bs.a_dg);
-                }
-                pr[0] = lane_gather(pr[0], ring_rev); pi[0] = lane_gather(pi[0], ring_rev);
-                lr[0] = lane_gather(lr[0], ring_rev); li[0] = lane_gather(li[0], ring_rev);
-                if (s == LD - 1) bs.template ahead<-1>(bl);
-                --sub;
-                double acc3[C::KW];
-#pragma unroll
-                for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
-                static_rfor<0, N>([&](auto q) {
-                    constexpr int Q = decltype(q)::value;
-                    ry_inv_with_inner<Q>(pr[0], pi[0], lr[0], li[0], bs.ry[s][Q], lane, acc3[3 * Q], acc3[3 * Q + 1], acc3[3 * Q + 2]);
-                    bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
-                });
-                const int vi = butterfly_sum<C::KW>(acc3, lane);
-                if (butterfly_owner<C::KW>(lane)) part_w[(long)sub * C::KW + vi] = acc3[0];
+        for (int s = LD - 1; s >= 0; --s) {
+            if (s != LD - 1) {
+                apply_phase<true>(pr[0], pi[0], bs.dg[s + 2]);
+                apply_phase<true>(lr[0], li[0], bs.dg[s + 2]);
+                bs.dg[s + 2] = bs.rd(nx, (s + 2) * kRecBytes + bs.a_dg);
             }
-            apply_phase<true>(pr[0], pi[0], bs.dg[1]);
-            apply_phase<true>(lr[0], li[0], bs.dg[1]);
-            bs.dg[1] = bs.rd(nx, kRecBytes + bs.a_dg);
-            col -= N;
-            const double2* cn = csrow + (col - N);
-            double gx[C::KX];
+            pr[0] = lane_gather(pr[0], ring_rev); pi[0] = lane_gather(pi[0], ring_rev);
+            lr[0] = lane_gather(lr[0], ring_rev); li[0] = lane_gather(li[0], ring_rev);
+            if (s == LD - 1) bs.template ahead_rel<-(kBDist + 1)>(sl, bl);
+            --sub;
+            double acc3[C::KW];
 #pragma unroll
-            for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
+            for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
             static_rfor<0, N>([&](auto q) {
                 constexpr int Q = decltype(q)::value;
-                enc_inv_with_inner<N, Q>(pr, pi, lr, li, bs.cs[Q], lane, gx[Q]);
-                bs.cs[Q] = cn[Q];
+                ry_inv_with_inner<Q>(pr[0], pi[0], lr[0], li[0], bs.ry[s][Q], lane, acc3[3 * Q], acc3[3 * Q + 1], acc3[3 * Q + 2]);
+                bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
             });
-            store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, col, N);
-            apply_phase<true>(pr[0], pi[0], bs.dg[0]);
-            apply_phase<true>(lr[0], li[0], bs.dg[0]);
-            bs.dg[0] = bs.rd(nx, bs.a_dg);
-            --bl;
+            const int vi = butterfly_sum<C::KW>(acc3, lane);
+            if (butterfly_owner<C::KW>(lane)) part_w[(long)sub * C::KW + vi] = acc3[0];
         }
+        apply_phase<true>(pr[0], pi[0], bs.dg[1]);
+        apply_phase<true>(lr[0], li[0], bs.dg[1]);
+        bs.dg[1] = bs.rd(nx, kRecBytes + bs.a_dg);
+        const double2* cn = cs_b - (kb + 1) * N;                  // the previous block's chunk
+        double gx[C::KX];
+#pragma unroll
+        for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
+        static_rfor<0, N>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            enc_inv_with_inner<N, Q>(pr, pi, lr, li, bs.cs[Q], lane, gx[Q]);
+            bs.cs[Q] = cn[Q];
+        });
+        store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, bl * N, N);
+        apply_phase<true>(pr[0], pi[0], bs.dg[0]);
+        apply_phase<true>(lr[0], li[0], bs.dg[0]);
+        bs.dg[0] = bs.rd(nx, bs.a_dg);
+    };
+    int bl = nb - 1;
+    for (; bl >= 0 && (bl & (kBSlots - 1)) != kBSlots - 1; --bl) {     // down to a block in the last slot
+        block(RtSlot{bl}, bl, 0);
+        cs_b -= N;
+    }
+    for (; bl >= kBSlots - 1; bl -= kBSlots) {                    // bl = 3 (mod 4): block bl - K sits in slot 3 - K
+        block(CtSlot<3>{}, bl, 0);
+        block(CtSlot<2>{}, bl - 1, 1);
+        block(CtSlot<1>{}, bl - 2, 2);
+        block(CtSlot<0>{}, bl - 3, 3);
+        cs_b -= kBSlots * N;
     }
 }
 
