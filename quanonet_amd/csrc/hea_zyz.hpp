@@ -1047,7 +1047,8 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) void bwd_ztri_kernel(ZBwd
                             gx[Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
                         }
                     });
-                    store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, col - ne + ch * N, m);
+                    if constexpr (N == 5) store_grad_x5(gx, lane, wave, a.B, E, a.grad_x, col - ne + ch * N, m);
+                    else store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, col - ne + ch * N, m);
                 }
                 col -= ne;
             }
@@ -1203,7 +1204,8 @@ __device__ __forceinline__ void zpacked_body(const ZBwdArgs& a, int wib, int lan
             enc_inv_with_inner<N, Q>(pr, pi, lr, li, bs.cs[Q], lane, gx[Q]);
             bs.cs[Q] = cn[Q];
         });
-        store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, bl * N, N);
+        if constexpr (N == 5) store_grad_x5(gx, lane, wave, a.B, E, a.grad_x, bl * N, N);
+        else store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, bl * N, N);
         apply_phase<true>(pr[0], pi[0], bs.dg[0]);
         apply_phase<true>(lr[0], li[0], bs.dg[0]);
         bs.dg[0] = bs.rd(nx, bs.a_dg);
