@@ -140,7 +140,7 @@ __device__ inline LayerInfo decode_layer(const Runs& r, int n, int l) {
 constexpr int kGmapDoubles = 8;
 __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, const double* __restrict__ w,
                                                       char* __restrict__ rec, char* __restrict__ srec,
-                                                      double* __restrict__ gmap, WorkspaceHeader* hdr) {
+                                                      double* __restrict__ gmap, double* __restrict__ emap, WorkspaceHeader* hdr) {
     const int l = blockIdx.x, j = threadIdx.x;
     if (l == 0 && j == 0) header_init(hdr);
     const LayerInfo cur = decode_layer(runs, n, l < L ? l : -1), prev = decode_layer(runs, n, l - 1);
@@ -155,6 +155,15 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
                 const double2 z = cmul(g.u, g.u);                    // e^{-i alpha}
                 double* gm = gmap + ((long)li.s * n + q) * kGmapDoubles;
                 gm[0] = g.cosb; gm[1] = g.sinb; gm[2] = g.cosc; gm[3] = g.sinc; gm[4] = z.x; gm[5] = -z.y;
+                // Sub-layer right after a full RX chunk: the chunk's gradients are read off THIS sub-layer's inner
+                // products (hea_zyz.hpp, bwd_ztri_kernel).  Between the two points lies W = prod_q RY(theta_q) RZ(beta_q),
+                // so Im<lam|X_q|psi> there = n . (X, Y, Z)_q here with n the axis of RY RZ X RZ^-1 RY^-1 =
+                // (cos beta cos theta, sin beta, -cos beta sin theta)  (the same for wire 4, whose gate runs as RY between
+                // RZ(+-pi/2): its Y there is that X).
+                const double2 zb = cmul(g.v, g.v);                   // e^{-i beta}
+                const double cb = zb.x, sb = -zb.y, ct = g.c * g.c - g.s * g.s, st = 2.0 * g.c * g.s;
+                double* em = emap + ((long)li.s * n + q) * 4;
+                em[0] = cb * ct; em[1] = sb; em[2] = -cb * st; em[3] = 0.0;
             }
         }
     }
@@ -358,7 +367,7 @@ int make_shape(int n, int nb, const int32_t* enc, const int32_t* ld, Shape& sh) 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t off_U, off_cs, off_part, off_rec, off_srec, off_gmap, total;
+    size_t off_U, off_cs, off_part, off_rec, off_srec, off_gmap, off_emap, total;
     long nwaves, nwaves_fwd;
     bool lds_fwd, lds_bwd, pair;
     bool zfwd, zfwd_shared, ztri, zpacked;   // ZYZ-form kernels of hea_zyz.hpp (n <= 5): forward (private / shared record ring),
@@ -475,6 +484,7 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     L.off_srec = p; p = align_up(p + (L.zsplit ? (size_t)(L.zL + 1 + 2 * kPadRecs) * kRecBytes : 0));
     if (L.zsplit) L.off_srec += (size_t)kPadRecs * kRecBytes;
     L.off_gmap = p; p = align_up(p + (zok ? (size_t)sh.blk * n * kGmapDoubles * sizeof(double) : 0));
+    L.off_emap = p; p = align_up(p + (zok ? (size_t)sh.blk * n * 4 * sizeof(double) : 0));
     L.total = p;
     return L;
 }
@@ -494,7 +504,7 @@ inline void profile_end(hipStream_t st) {
 int launch_prep_zyz(int n, const Shape& sh, const double* w, char* ws, const Layout& L, hipStream_t st) {
     hipLaunchKernelGGL(prep_zyz_kernel, dim3((unsigned)(L.zL + 1)), dim3(64), 0, st, sh.runs, n, L.zL, w,
                        ws + L.off_rec, L.zsplit ? ws + L.off_srec : nullptr, reinterpret_cast<double*>(ws + L.off_gmap),
-                       reinterpret_cast<WorkspaceHeader*>(ws));
+                       reinterpret_cast<double*>(ws + L.off_emap), reinterpret_cast<WorkspaceHeader*>(ws));
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 int launch_zyz_forward(int n, const Shape& sh, int64_t B, const Layout& L, char* ws, const AngleSrc& src, double off, double co,
@@ -540,7 +550,8 @@ int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char
     const ZBwdArgs za{sh.runs, (long)B, (int)sh.E, (int)sh.blk, ws + L.off_rec, (int)((L.zL + 1) * kRecBytes), L.zL, src, off, co,
                       diag, pauli, g, state_in, y, bias, inv_bt, out, grad_x, partial,
                       &reinterpret_cast<WorkspaceHeader*>(ws)->status, fast, nblocks,
-                      (L.zsplit && !L.zpacked) ? ws + L.off_srec : nullptr, L.zpipes};
+                      (L.zsplit && !L.zpacked) ? ws + L.off_srec : nullptr, L.zpipes,
+                      reinterpret_cast<const double*>(ws + L.off_emap)};
     const size_t dyn = (size_t)(64 >> n) * zyz_cs_row(n, sh.E) * sizeof(double2);
     if (L.zpacked) {
         switch (n) {

@@ -155,10 +155,7 @@ template <int CNT>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CNT) : "memory"); }
 
 constexpr int kSlots = 8, kDist = 6;
-#ifndef QHEA_ZSIGMA
-#define QHEA_ZSIGMA 2
-#endif
-constexpr int kZSigma = QHEA_ZSIGMA;            // sigma waves per workgroup of bwd_ztri_kernel: step t belongs to wave t % kZSigma
+constexpr int kZSigma = 2;                      // sigma waves per pipeline of bwd_ztri_kernel (3 or 4 do not fit: DESIGN.md 3.4)
 struct ZSync { int psi_prod, lam_prod, ready, abort; int cursor[kZSigma]; };
 constexpr int kRecRingBytes = kSlots * kRecBytes;           // per streaming wave
 
@@ -615,6 +612,7 @@ struct ZBwdArgs {
     int fast_ld, nblocks;
     const char* srec;           // split records for the forward phase, nullptr: all-lane forward sweep
     int pipes;                  // bwd_ztri_kernel: sample groups per workgroup (1 or 2)
+    const double* emap;         // per ansatz gate 4 doubles: axis that maps its (X, Y, Z) sums to the preceding RX gate's gradient
 };
 
 // kWaves sweeping waves + kFwdHelpers waves that only help to fill the (cos, sin) tables and then leave: the fill is
@@ -833,9 +831,8 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
-            apply_phase<true>(sr[0], si[0], bs.dg[1]);
-            bs.dg[1] = bs.rd(nx, kRecBytes + bs.a_dg);
-            publish();
+            apply_phase<true>(sr[0], si[0], bs.dg[1]);     // (no publication here: the RX chunk's gradients are read off
+            bs.dg[1] = bs.rd(nx, kRecBytes + bs.a_dg);     //  the inner products of the sub-layer just undone, see the sigma waves)
             const double2* cn = cs_b - (kb + 1) * (N * CW);   // the previous block's chunk
             static_rfor<0, N>([&](auto q) {
                 constexpr int Q = decltype(q)::value;
@@ -991,6 +988,31 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) void bwd_ztri_kernel(ZBwd
         const int me = role - 2;
         int seen_p = 0, seen_l = 0;
         int col = E, sub = a.blk, step = 0;
+        // Block-unrolled shapes (every block: one full RX chunk + LD sub-layers): the chains do not publish at the RX chunk.
+        // With psi_C = W psi_E, lambda_C = W lambda_E, W = prod_q RY(theta_q) RZ(beta_q) the layer between the chunk (E) and
+        // the block's first sub-layer's publication point (C):  Im<lam_E|X_q|psi_E> = n_q . (X, Y, Z)_q at C, n_q batch
+        // invariant (prep_zyz_kernel, `emap`) -- so the chunk's gradients are a per-lane combination of the products this
+        // sub-layer forms anyway, summed per sample: one pipeline step and two publications less per block.
+        const bool merged = a.fast_ld != 0;
+        // Which sigma wave takes step t.  Plain alternation, except for merged blocks of two sub-layers: there every second
+        // step carries the chunk's gradients as well, and plain alternation would hand all of those to the same wave --
+        // the owner pattern 0 1 1 0 | 0 1 1 0 ... alternates them.
+        static_assert(kZSigma == 2, "owner pattern and coefficient prefetch below");
+        const bool skew = merged && a.fast_ld == 2;
+        auto owner = [&](int t) { return skew ? ((t + (t >> 1)) & 1) : (t & 1); };
+        auto next_owned = [&](int t) { int u = t + 1; while (owner(u) != me) ++u; return u; };   // at most 3 tries
+        // Either way a wave owns the chunk-carrying step of every OTHER block, so it fetches the axis coefficients of its next
+        // such block (two blocks on) right after it has used the current ones: a fetch at the point of use would put a global
+        // round trip into the step (measured: +5 us per launch).
+        double em[3 * N];
+        auto load_em = [&](int sub0) {                     // sub-layer sub0's gates; wave-uniform address
+            const double* __restrict__ e = a.emap + (long)(sub0 < 0 ? 0 : sub0) * N * 4;
+            static_for<0, N>([&](auto q) {
+                constexpr int Q = decltype(q)::value;
+                em[3 * Q] = e[4 * Q]; em[3 * Q + 1] = e[4 * Q + 1]; em[3 * Q + 2] = e[4 * Q + 2];
+            });
+        };
+        if (merged) load_em(a.blk - ((owner(a.fast_ld - 1) == me ? 0 : 1) + 1) * a.fast_ld);
         for (int ri = a.runs.nruns - 1; ri >= 0; --ri) {
             const int ne = a.runs.enc[ri], nld = a.runs.ld[ri];
             const int nch = (ne + N - 1) / N;
@@ -998,7 +1020,7 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) void bwd_ztri_kernel(ZBwd
             for (int rep = 0; rep < a.runs.count[ri]; ++rep) {
                 for (int s = nld - 1; s >= 0; --s) {
                     --sub;
-                    if (step % kZSigma != me) { ++step; continue; }
+                    if (owner(step) != me) { ++step; continue; }
                     pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
                     pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
                     const double2* slot = psi_ring[step & (RING - 1)];
@@ -1006,7 +1028,7 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) void bwd_ztri_kernel(ZBwd
                     double2 qv[N];
                     static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
                     const double2 lm = lam_ring[step & (RING - 1)][lane];
-                    __hip_atomic_store(&sync.cursor[me], step + kZSigma, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&sync.cursor[me], next_owned(step), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ++step;
                     double acc3[C::KW];
 #pragma unroll
@@ -1018,22 +1040,37 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) void bwd_ztri_kernel(ZBwd
                         acc3[3 * Q + 1] = -sg * (lm.x * qv[Q].x + lm.y * qv[Q].y);
                         acc3[3 * Q + 2] = sg * (lm.x * p.y - lm.y * p.x);
                     });
+                    double gx[C::KX];
+                    if (merged && s == 0) {
+#pragma unroll
+                        for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
+                        static_for<0, N>([&](auto q) {
+                            constexpr int Q = decltype(q)::value;
+                            gx[Q] = em[3 * Q] * acc3[3 * Q] + em[3 * Q + 1] * acc3[3 * Q + 1] + em[3 * Q + 2] * acc3[3 * Q + 2];
+                        });
+                        load_em(sub - 2 * nld);               // this wave's next chunk-carrying step
+                    }
                     const int vi = butterfly_sum<C::KW>(acc3, lane);
                     if (butterfly_owner<C::KW>(lane)) {
                         if constexpr (PIPES == 1) part_w[(long)sub * C::KW + vi] = acc3[0];
                         else __hip_atomic_fetch_add(&row_lds[sub * C::KW + vi], acc3[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+                    if (merged && s == 0) {
+                        if constexpr (N == 5) store_grad_x5(gx, lane, wave, a.B, E, a.grad_x, col - ne, N);
+                        else store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, col - ne, N);
+                    }
                 }
                 for (int ch = nch - 1; ch >= 0; --ch) {
+                    if (merged) continue;                     // (its gradients came with sub-layer 0 above)
                     const int m = ch == nch - 1 ? m_last : N;
-                    if (step % kZSigma != me) { ++step; continue; }
+                    if (owner(step) != me) { ++step; continue; }
                     pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
                     pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
                     const double2* slot = psi_ring[step & (RING - 1)];
                     double2 qv[N];
                     static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
                     const double2 lm = lam_ring[step & (RING - 1)][lane];
-                    __hip_atomic_store(&sync.cursor[me], step + kZSigma, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&sync.cursor[me], next_owned(step), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ++step;
                     double gx[C::KX];
 #pragma unroll
