@@ -469,7 +469,7 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     L.zpipes = 1;
     if (L.ztri && var == QHEA_BWD_ZTRI2 && L.nwaves > (long)simd_count() / 4) {
         const size_t cs_bytes = (size_t)(64 >> n) * zyz_cs_row(n, sh.E) * (L.zsplit ? 32 : 16);
-        const size_t lds = 2 * (2 * (size_t)kBlockRingBytes + 2 * (size_t)kZRingDepth<2> * 1024 + 1024 + 64) + 2 * cs_bytes +
+        const size_t lds = 2 * ztri_fixed_lds(kZRingDepth<2>) + 2 * cs_bytes +
                            (size_t)sh.blk * padded_3n(n) * sizeof(double);
         if (lds <= 158 * 1024) { L.zpipes = 2; L.nwaves = (L.nwaves + 1) / 2; }      // one partial row per workgroup
     }
@@ -562,7 +562,7 @@ int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char
         }
         return QHEA_OK;
     }
-    const size_t dyn_tri = (size_t)L.zpipes * (za.srec ? 2 * dyn : dyn) +
+    const size_t dyn_tri = (size_t)L.zpipes * (ztri_fixed_lds(L.zpipes == 2 ? kZRingDepth<2> : kZRingDepth<1>) + (za.srec ? 2 * dyn : dyn)) +
                            (L.zpipes == 2 ? (size_t)sh.blk * padded_3n(n) * sizeof(double) : 0);
     switch (n) {
 #define QHEA_CASE(NN) case NN: launch_bwd_ztri_##NN(dim3((unsigned)L.nwaves), dyn_tri, st, za); break;

@@ -155,7 +155,15 @@ template <int CNT>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CNT) : "memory"); }
 
 constexpr int kSlots = 8, kDist = 6;
-constexpr int kZSigma = 2;                      // sigma waves per pipeline of bwd_ztri_kernel (3 or 4 do not fit: DESIGN.md 3.4)
+// sigma waves per pipeline of bwd_ztri_kernel.  The sigma waves bound the reverse phase (they never wait for the chains after
+// their first step, the chains do wait for ring slots: DESIGN.md 3.4), so a third one pays -- once two 5-wave workgroups fit
+// a CU, which takes <= 128 VGPRs (four wave slots per SIMD; the kernel's LDS is all dynamic so that the compiler does not cap
+// its occupancy estimate at the LDS limit, and the walks keep one layer's coefficients ahead instead of a block's).
+// cfg 2, us per launch with 2 / 3 / 4 sigma waves: B = 512 78.5 / 72.1 / 70.8, B = 1024 98.7 / 92.0 / 96.8, B = 1536 159 / 143 / 166.
+#ifndef QHEA_ZSIGMA
+#define QHEA_ZSIGMA 3
+#endif
+constexpr int kZSigma = QHEA_ZSIGMA;
 struct ZSync { int psi_prod, lam_prod, ready, abort; int cursor[kZSigma]; };
 constexpr int kRecRingBytes = kSlots * kRecBytes;           // per streaming wave
 
@@ -336,6 +344,11 @@ struct BlockStream {
         if (!SHARED || loader) wait_vmcnt<(kBDist - 1) * RPB>();
         if constexpr (SHARED) __syncthreads();
     }
+    // the same check placed AFTER the block's ahead_rel (one more block in flight)
+    __device__ __forceinline__ void landed_late() const {
+        if (!SHARED || loader) wait_vmcnt<kBDist * RPB>();
+        if constexpr (SHARED) __syncthreads();
+    }
     template <int D>
     __device__ __forceinline__ void ahead(int b) const { if (!SHARED || loader) issue(b + (kBDist + 1) * D); }
     template <int D>
@@ -382,45 +395,62 @@ __host__ __device__ inline int zyz_fast_ld(const Runs& r, int n) {      // LD of
     return ld;
 }
 
+// One layer's coefficients in registers: the diagonal applied before it and its N gates' (variant of this lane).
+template <int N>
+struct LayerCoef { double2 dg; double2 g[N]; };
+
 template <int N, int LD, class BS>
 __device__ __forceinline__ void zyz_forward_fast(double (&re)[1], double (&im)[1], const Runs& runs, BS& bs,
                                                  const double2* __restrict__ csrow, int E, int lane, int klow, int ring_fwd) {
     re[0] = klow == 0 ? 1.0 : 0.0;
     im[0] = 0.0;
     bs.template prime<1>(0, false);
-    bs.load_records(bs.slot(0));
-    bs.load_cs(csrow, 0);
     int nblocks = 0;                                      // every block has enc = n (zyz_fast_ld)
     for (int ri = 0; ri < runs.nruns; ++ri) nblocks += runs.count[ri];
     const double2* cs_b = csrow;                          // first column of the unrolled body's first block
-    // Every coefficient register is refilled with the next block's value right after its last use, and the scheduler
-    // is kept from sinking those LDS reads towards the ring gather (sched_barrier): queued in front of the gather they
-    // would add their service time to its latency, which the chain waits out.
-    auto block = [&](auto sl, int b, int kb) {
-        bs.landed();
-        const char* nx = bs.template slot_rel<1>(sl);
-        apply_phase<false>(re[0], im[0], bs.dg[0]);
-        bs.dg[0] = bs.rd(nx, bs.a_dg);
+    // Coefficients are read ONE LAYER ahead, all of a layer's at its predecessor's start (the block walk used to keep a
+    // whole block's 18 coefficients in registers: 72 VGPRs, which capped the pipeline kernel at three waves per SIMD):
+    // the reads run under the predecessor's gates, well clear of the ring gather at its end.
+    LayerCoef<N> ce, ca, cb;                              // RX chunk, sub-layer 1, sub-layer 2
+    ce.dg = bs.rd(bs.slot(0), bs.a_dg);
+    static_for<0, N>([&](auto q) { ce.g[decltype(q)::value] = cs_b[decltype(q)::value]; });
+    auto read_layer = [&](LayerCoef<N>& c, const char* sl, int rec) {
+        c.dg = bs.rd(sl, rec * kRecBytes + bs.a_dg);
+        static_for<0, N>([&](auto q) { c.g[decltype(q)::value] = bs.rd(sl, rec * kRecBytes + bs.a_ry[decltype(q)::value]); });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto read_chunk = [&](const char* nx, int kb) {       // the next block's RX chunk + the diagonal in front of it
+        ce.dg = bs.rd(nx, bs.a_dg);
         const double2* cn = cs_b + (kb + 1) * N;
-        static_for<0, N>([&](auto q) {
-            constexpr int Q = decltype(q)::value;
-            apply_enc<N, Q, false>(re, im, bs.cs[Q]);
-            bs.cs[Q] = cn[Q];
+        static_for<0, N>([&](auto q) { ce.g[decltype(q)::value] = cn[decltype(q)::value]; });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto ry_layer = [&](const LayerCoef<N>& c) {
+        apply_phase<false>(re[0], im[0], c.dg);
+        static_for<0, N>([&](auto q) { apply_ry<decltype(q)::value, false>(re[0], im[0], c.g[decltype(q)::value]); });
+        __builtin_amdgcn_sched_barrier(0);
+        re[0] = lane_gather(re[0], ring_fwd);
+        im[0] = lane_gather(im[0], ring_fwd);
+    };
+    auto block = [&](auto sl, int b, int kb) {
+        const char* cur = bs.template slot_rel<0>(sl);
+        const char* nx = bs.template slot_rel<1>(sl);
+        read_layer(ca, cur, 1);
+        apply_phase<false>(re[0], im[0], ce.dg);
+        static_for<0, N>([&](auto q) { apply_enc<N, decltype(q)::value, false>(re, im, ce.g[decltype(q)::value]); });
+        if constexpr (LD == 2) {
+            read_layer(cb, cur, 2);
+            ry_layer(ca);
+            bs.template ahead_rel<kBDist + 1>(sl, b);     // in the gather's shadow
             __builtin_amdgcn_sched_barrier(0);
-        });
-#pragma unroll
-        for (int s = 0; s < LD; ++s) {
-            apply_phase<false>(re[0], im[0], bs.dg[1 + s]);
-            bs.dg[1 + s] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_dg);
-            static_for<0, N>([&](auto q) {
-                constexpr int Q = decltype(q)::value;
-                apply_ry<Q, false>(re[0], im[0], bs.ry[s][Q]);
-                bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            re[0] = lane_gather(re[0], ring_fwd);
-            im[0] = lane_gather(im[0], ring_fwd);
-            if (s == 0) bs.template ahead_rel<kBDist + 1>(sl, b);      // in the gather's shadow
+            bs.landed_late();                             // block b + 1 landed
+            read_chunk(nx, kb);
+            ry_layer(cb);
+        } else {
+            bs.landed();                                  // block b + 1 landed
+            read_chunk(nx, kb);
+            ry_layer(ca);
+            bs.template ahead_rel<kBDist + 1>(sl, b);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -436,7 +466,7 @@ __device__ __forceinline__ void zyz_forward_fast(double (&re)[1], double (&im)[1
         block(RtSlot{b}, b, 0);
         cs_b += N;
     }
-    apply_phase<false>(re[0], im[0], bs.dg[0]);        // record L = record 0 of the slot after the last block
+    apply_phase<false>(re[0], im[0], ce.dg);           // record L = record 0 of the slot after the last block
 }
 
 // ---------------------------------------------------------------------------------------
@@ -553,33 +583,45 @@ template <int LD>
 __device__ __forceinline__ double zsplit_forward(SplitStream<LD>& bs, const char* csrow, int nblocks, int lane, int ring_fwd) {
     double x = lane == 0 ? 1.0 : 0.0;
     bs.template prime<1>(0, false);
-    bs.load_records_split(bs.slot(0));
-    bs.load_cs_split(csrow);
     const char* cs_b = csrow;                            // entry of block b's first column
-    auto block = [&](auto sl, int b, int kb) {           // block b = the unrolled body's block kb (its cs entries: immediates)
-        bs.landed();
-        const char* nx = bs.template slot_rel<1>(sl);
-        split_phase(x, bs.dg[0]);
-        bs.dg[0] = bs.rd8(nx, bs.a_dg);
+    LayerCoef<5> ce, ca, cb;                             // coefficients one layer ahead (zyz_forward_fast)
+    ce.dg = bs.rd8(bs.slot(0), bs.a_dg);
+    static_for<0, 5>([&](auto q) { ce.g[decltype(q)::value] = bs.rd(cs_b, bs.a_cs[decltype(q)::value]); });
+    auto read_layer = [&](LayerCoef<5>& c, const char* sl, int rec) {
+        c.dg = bs.rd8(sl, rec * kRecBytes + bs.a_dg);
+        static_for<0, 5>([&](auto q) { c.g[decltype(q)::value] = bs.rd(sl, rec * kRecBytes + bs.a_ry[decltype(q)::value]); });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto read_chunk = [&](const char* nx, int kb) {
+        ce.dg = bs.rd8(nx, bs.a_dg);
         const char* cn = cs_b + (kb + 1) * (5 * 32);
-        static_for<0, 5>([&](auto q) {
-            constexpr int Q = decltype(q)::value;
-            split_ry<Q>(x, bs.cs[Q]);
-            bs.cs[Q] = bs.rd(cn, bs.a_cs[Q]);
+        static_for<0, 5>([&](auto q) { ce.g[decltype(q)::value] = bs.rd(cn, bs.a_cs[decltype(q)::value]); });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto layer = [&](const LayerCoef<5>& c, bool ring) {
+        split_phase(x, c.dg);
+        static_for<0, 5>([&](auto q) { split_ry<decltype(q)::value>(x, c.g[decltype(q)::value]); });
+        __builtin_amdgcn_sched_barrier(0);
+        if (ring) x = lane_gather(x, ring_fwd);
+    };
+    auto block = [&](auto sl, int b, int kb) {           // block b = the unrolled body's block kb (its cs entries: immediates)
+        const char* cur = bs.template slot_rel<0>(sl);
+        const char* nx = bs.template slot_rel<1>(sl);
+        read_layer(ca, cur, 1);
+        layer(ce, false);
+        if constexpr (LD == 2) {
+            read_layer(cb, cur, 2);
+            layer(ca, true);
+            bs.template ahead_rel<kBDist + 1>(sl, b);    // in the gather's shadow
             __builtin_amdgcn_sched_barrier(0);
-        });
-#pragma unroll
-        for (int s = 0; s < LD; ++s) {
-            split_phase(x, bs.dg[1 + s]);
-            bs.dg[1 + s] = bs.rd8(nx, (1 + s) * kRecBytes + bs.a_dg);
-            static_for<0, 5>([&](auto q) {
-                constexpr int Q = decltype(q)::value;
-                split_ry<Q>(x, bs.ry[s][Q]);
-                bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            x = lane_gather(x, ring_fwd);
-            if (s == 0) bs.template ahead_rel<kBDist + 1>(sl, b);      // in the gather's shadow
+            bs.landed_late();
+            read_chunk(nx, kb);
+            layer(cb, true);
+        } else {
+            bs.landed();
+            read_chunk(nx, kb);
+            layer(ca, true);
+            bs.template ahead_rel<kBDist + 1>(sl, b);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -595,7 +637,7 @@ __device__ __forceinline__ double zsplit_forward(SplitStream<LD>& bs, const char
         block(RtSlot{b}, b, 0);
         cs_b += 5 * 32;
     }
-    split_phase(x, bs.dg[0]);                            // record L = record 0 of the slot after the last block
+    split_phase(x, ce.dg);                               // record L = record 0 of the slot after the last block
     return x;
 }
 
@@ -801,48 +843,59 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
         bs.template prime<-1>(nb, true);                      // (drain: the forward sweep's run-ahead fetches target the same slots)
         apply_phase<true>(sr[0], si[0], bs.rd(bs.slot(nb), bs.a_dg));     // block nb's slot: its record 0 is the final diagonal
         bs.template step<-1>(nb);                             // block nb-1 landed
-        bs.load_records(bs.slot(nb - 1));
         constexpr int CW = SPLIT ? 2 : 1;                     // double2 per table column
-        auto load_chunk = [&](const double2* chunk) {         // the RX chunk whose first column's entry is `chunk`
-            if constexpr (SPLIT) static_for<0, N>([&](auto q) { bs.cs[decltype(q)::value] = cs32_packed<decltype(q)::value>(chunk); });
-            else static_for<0, N>([&](auto q) { bs.cs[decltype(q)::value] = chunk[decltype(q)::value]; });
-        };
         const double2* cs_b = csrow + (long)(nb - 1) * N * CW;    // chunk of the block at hand (every block has enc = n)
-        load_chunk(cs_b);
+        // coefficients one layer ahead (zyz_forward_fast): ct = the block's last sub-layer (record LD), cm = its first one
+        // when LD = 2 (record 1), c0 = its RX chunk with the diagonal in front of it (record 0)
+        LayerCoef<N> ct, cm, c0;
+        auto read_layer = [&](LayerCoef<N>& c, const char* sl, int rec) {
+            c.dg = bs.rd(sl, rec * kRecBytes + bs.a_dg);
+            static_for<0, N>([&](auto q) { c.g[decltype(q)::value] = bs.rd(sl, rec * kRecBytes + bs.a_ry[decltype(q)::value]); });
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto read_chunk = [&](const char* sl, const double2* chunk) {
+            c0.dg = bs.rd(sl, bs.a_dg);
+            if constexpr (SPLIT) static_for<0, N>([&](auto q) { c0.g[decltype(q)::value] = cs32_packed<decltype(q)::value>(chunk); });
+            else static_for<0, N>([&](auto q) { c0.g[decltype(q)::value] = chunk[decltype(q)::value]; });
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto undo_ry = [&](const LayerCoef<N>& c) {            // ring^-1, publish, RY^-1 of a sub-layer
+            sr[0] = lane_gather(sr[0], ring_rev);
+            si[0] = lane_gather(si[0], ring_rev);
+        };
+        read_layer(ct, bs.slot(nb - 1), LD);
         // one block, sitting in ring slot `sl`; kb: its position in the unrolled body (cs_b stays on the body's first block)
         auto block = [&](auto sl, int bl, int kb) {
-            bs.landed();                                  // block bl-1 landed
+            const char* cur = bs.template slot_rel<0>(sl);
             const char* nx = bs.template slot_rel<-1>(sl);
-#pragma unroll
-            for (int s = LD - 1; s >= 0; --s) {
-                if (s != LD - 1) {                        // (the diagonal after the block's last sub-layer was undone
-                    apply_phase<true>(sr[0], si[0], bs.dg[s + 2]);     //  at the end of the previous block)
-                    bs.dg[s + 2] = bs.rd(nx, (s + 2) * kRecBytes + bs.a_dg);
-                }
-                sr[0] = lane_gather(sr[0], ring_rev);
-                si[0] = lane_gather(si[0], ring_rev);
-                if (s == LD - 1) bs.template ahead_rel<-(kBDist + 1)>(sl, bl);   // in the gather's shadow
+            // ---- last sub-layer: ring^-1, publish, RY^-1, then the diagonal in front of it
+            if constexpr (LD == 2) read_layer(cm, cur, 1);
+            else read_chunk(cur, cs_b - kb * (N * CW));
+            undo_ry(ct);
+            bs.template ahead_rel<-(kBDist + 1)>(sl, bl);     // in the gather's shadow
+            __builtin_amdgcn_sched_barrier(0);
+            publish();
+            static_rfor<0, N>([&](auto q) { apply_ry<decltype(q)::value, true>(sr[0], si[0], ct.g[decltype(q)::value]); });
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LD == 2) {
+                read_chunk(cur, cs_b - kb * (N * CW));
+                apply_phase<true>(sr[0], si[0], ct.dg);
+                undo_ry(cm);
                 __builtin_amdgcn_sched_barrier(0);
                 publish();
-                static_rfor<0, N>([&](auto q) {
-                    constexpr int Q = decltype(q)::value;
-                    apply_ry<Q, true>(sr[0], si[0], bs.ry[s][Q]);
-                    bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            }
-            apply_phase<true>(sr[0], si[0], bs.dg[1]);     // (no publication here: the RX chunk's gradients are read off
-            bs.dg[1] = bs.rd(nx, kRecBytes + bs.a_dg);     //  the inner products of the sub-layer just undone, see the sigma waves)
-            const double2* cn = cs_b - (kb + 1) * (N * CW);   // the previous block's chunk
-            static_rfor<0, N>([&](auto q) {
-                constexpr int Q = decltype(q)::value;
-                apply_enc<N, Q, true>(sr, si, bs.cs[Q]);
-                if constexpr (SPLIT) bs.cs[Q] = cs32_packed<Q>(cn);
-                else bs.cs[Q] = cn[Q];
+                static_rfor<0, N>([&](auto q) { apply_ry<decltype(q)::value, true>(sr[0], si[0], cm.g[decltype(q)::value]); });
                 __builtin_amdgcn_sched_barrier(0);
-            });
-            apply_phase<true>(sr[0], si[0], bs.dg[0]);    // the diagonal in front of this block's RX chunk: every
-            bs.dg[0] = bs.rd(nx, bs.a_dg);                // diagonal a block undoes is one of its own records
+                apply_phase<true>(sr[0], si[0], cm.dg);
+            } else {
+                apply_phase<true>(sr[0], si[0], ct.dg);
+            }
+            // ---- RX chunk (no publication: its gradients are read off the sub-layer just undone, see the sigma waves);
+            //      meanwhile the next block's last sub-layer comes in
+            bs.landed_late();                                 // block bl - 1 landed
+            read_layer(ct, nx, LD);
+            static_rfor<0, N>([&](auto q) { apply_enc<N, decltype(q)::value, true>(sr, si, c0.g[decltype(q)::value]); });
+            __builtin_amdgcn_sched_barrier(0);
+            apply_phase<true>(sr[0], si[0], c0.dg);           // the diagonal in front of this block's RX chunk
         };
         int bl = nb - 1;
         for (; bl >= 0 && (bl & (kBSlots - 1)) != kBSlots - 1; --bl) {     // down to a block in the last slot
@@ -920,29 +973,35 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
 // row held in LDS (two addends per element: the order cannot matter), written out once at the end -- half the
 // partial rows for the reduce kernel to read.  Chosen when two workgroups would share a CU anyway (hea_api.hip).
 constexpr int kZPipeWaves = 2 + kZSigma;
+// LDS of one pipeline apart from its (cos, sin) table: two record rings, psi and lambda hand-off rings, psi_N, counters
+__host__ __device__ constexpr size_t ztri_fixed_lds(int ring) { return 2 * (size_t)kBlockRingBytes + 2 * (size_t)ring * 1024 + 1024 + 64; }
+template <int PIPES>
+__device__ __forceinline__ int pipe_of_wave() {
+    return PIPES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) / kZPipeWaves;
+}
 template <int PIPES> constexpr int kZRingDepth = PIPES == 1 ? kPairRing : 8;      // LDS: 2 x (24 + 16 + 20) KB + the row
 template <int N, int PIPES>
-__global__ __launch_bounds__(64 * kZPipeWaves * PIPES) void bwd_ztri_kernel(ZBwdArgs a) {
+__global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_waves_per_eu(4, 4))) void bwd_ztri_kernel(ZBwdArgs a) {
     using C = Cfg<N>;
     static_assert(C::R == 1, "all-lane layout");
     constexpr int RING = kZRingDepth<PIPES>;
-    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // PIPES x SPW x E (cos, sin) [+ the shared row]
-    __shared__ __attribute__((aligned(16))) char rec_ring_all[PIPES][2 * kBlockRingBytes];
-    __shared__ double2 psi_ring_all[PIPES][RING][64];
-    __shared__ double2 lam_ring_all[PIPES][RING][64];
-    __shared__ double2 psi_final_all[PIPES][64];
-    __shared__ ZSync sync_all[PIPES];
+    // All of the kernel's LDS is dynamic -- per pipeline [record rings | psi ring | lambda ring | psi_N | sync], then the
+    // (cos, sin) tables [+ the shared row]: with a static part the compiler concludes that LDS caps the occupancy at two
+    // waves per SIMD and gives the register allocation 256 VGPRs to play with.
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    char* fixed = dyn_lds + pipe_of_wave<PIPES>() * (int)ztri_fixed_lds(RING);
+    char* lds_tables = dyn_lds + PIPES * (int)ztri_fixed_lds(RING);
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int pipe = PIPES == 1 ? 0 : wv / kZPipeWaves;
     const int role = PIPES == 1 ? wv : wv % kZPipeWaves;                           // 0: psi, 1: lambda, 2..: sigma
     const int tid = (int)threadIdx.x - pipe * (64 * kZPipeWaves);                  // within the pipeline
-    char* rec_ring = rec_ring_all[pipe];
-    double2 (*psi_ring)[64] = psi_ring_all[pipe];
-    double2 (*lam_ring)[64] = lam_ring_all[pipe];
-    double2* psi_final = psi_final_all[pipe];
-    ZSync& sync = sync_all[pipe];
+    char* rec_ring = fixed;
+    double2 (*psi_ring)[64] = reinterpret_cast<double2 (*)[64]>(fixed + 2 * kBlockRingBytes);
+    double2 (*lam_ring)[64] = reinterpret_cast<double2 (*)[64]>(fixed + 2 * kBlockRingBytes + RING * 1024);
+    double2* psi_final = reinterpret_cast<double2*>(fixed + 2 * kBlockRingBytes + 2 * RING * 1024);
+    ZSync& sync = *reinterpret_cast<ZSync*>(fixed + 2 * kBlockRingBytes + 2 * RING * 1024 + 1024);
     const long wave = (long)blockIdx.x * PIPES + pipe;                            // one sample group per pipeline; a group past
     const long b_raw = wave * C::SPW + (lane >> C::LB);                           // the batch runs on copies of the last sample
     const bool valid = b_raw < a.B;                                               // with lambda = 0
@@ -956,8 +1015,8 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) void bwd_ztri_kernel(ZBwd
     }
     const bool split = N == 5 && a.srec != nullptr && a.fast_ld != 0;
     const int cs_bytes = (int)(C::SPW * zyz_cs_row(N, E) * (split ? 32 : 16));
-    double2* cs = reinterpret_cast<double2*>(dyn_lds + pipe * cs_bytes);
-    double* row_lds = reinterpret_cast<double*>(dyn_lds + PIPES * cs_bytes);       // PIPES = 2: blk x KW sums of both groups
+    double2* cs = reinterpret_cast<double2*>(lds_tables + pipe * cs_bytes);
+    double* row_lds = reinterpret_cast<double*>(lds_tables + PIPES * cs_bytes);    // PIPES = 2: blk x KW sums of both groups
     if constexpr (PIPES > 1) {
         for (int i = (int)threadIdx.x; i < a.blk * C::KW; i += 64 * kZPipeWaves * PIPES) row_lds[i] = 0.0;
     }
@@ -995,15 +1054,15 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) void bwd_ztri_kernel(ZBwd
         // sub-layer forms anyway, summed per sample: one pipeline step and two publications less per block.
         const bool merged = a.fast_ld != 0;
         // Which sigma wave takes step t.  Plain alternation, except for merged blocks of two sub-layers: there every second
-        // step carries the chunk's gradients as well, and plain alternation would hand all of those to the same wave --
-        // the owner pattern 0 1 1 0 | 0 1 1 0 ... alternates them.
-        static_assert(kZSigma == 2, "owner pattern and coefficient prefetch below");
-        const bool skew = merged && a.fast_ld == 2;
-        auto owner = [&](int t) { return skew ? ((t + (t >> 1)) & 1) : (t & 1); };
-        auto next_owned = [&](int t) { int u = t + 1; while (owner(u) != me) ++u; return u; };   // at most 3 tries
-        // Either way a wave owns the chunk-carrying step of every OTHER block, so it fetches the axis coefficients of its next
-        // such block (two blocks on) right after it has used the current ones: a fetch at the point of use would put a global
-        // round trip into the step (measured: +5 us per launch).
+        // step carries the chunk's gradients as well, and with an even number of sigma waves plain rotation would hand all of
+        // those to the same waves -- the owner (t + t/2) mod kZSigma (0 1 1 0 | 0 1 1 0 ... for two waves) rotates them too.
+        static_assert(kZSigma >= 2 && kZSigma <= 4, "owner pattern and coefficient prefetch below");
+        const bool skew = merged && a.fast_ld == 2 && kZSigma % 2 == 0;
+        auto owner = [&](int t) { return skew ? (t + (t >> 1)) % kZSigma : t % kZSigma; };
+        auto next_owned = [&](int t) { int u = t + 1; while (owner(u) != me) ++u; return u; };   // at most kZSigma + 1 tries
+        // Either way a wave owns the chunk-carrying step of every kZSigma-th block, so it fetches the axis coefficients of its
+        // next such block right after it has used the current ones: a fetch at the point of use would put a global round
+        // trip into the step (measured: +5 us per launch).
         double em[3 * N];
         auto load_em = [&](int sub0) {                     // sub-layer sub0's gates; wave-uniform address
             const double* __restrict__ e = a.emap + (long)(sub0 < 0 ? 0 : sub0) * N * 4;
@@ -1012,7 +1071,11 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) void bwd_ztri_kernel(ZBwd
                 em[3 * Q] = e[4 * Q]; em[3 * Q + 1] = e[4 * Q + 1]; em[3 * Q + 2] = e[4 * Q + 2];
             });
         };
-        if (merged) load_em(a.blk - ((owner(a.fast_ld - 1) == me ? 0 : 1) + 1) * a.fast_ld);
+        if (merged) {
+            int j0 = 0;                                        // first block (in walking order) whose chunk-carrying step is mine
+            while (owner(j0 * a.fast_ld + a.fast_ld - 1) != me) ++j0;
+            load_em(a.blk - (j0 + 1) * a.fast_ld);
+        }
         for (int ri = a.runs.nruns - 1; ri >= 0; --ri) {
             const int ne = a.runs.enc[ri], nld = a.runs.ld[ri];
             const int nch = (ne + N - 1) / N;
@@ -1048,7 +1111,7 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) void bwd_ztri_kernel(ZBwd
                             constexpr int Q = decltype(q)::value;
                             gx[Q] = em[3 * Q] * acc3[3 * Q] + em[3 * Q + 1] * acc3[3 * Q + 1] + em[3 * Q + 2] * acc3[3 * Q + 2];
                         });
-                        load_em(sub - 2 * nld);               // this wave's next chunk-carrying step
+                        load_em(sub - kZSigma * nld);         // this wave's next chunk-carrying step
                     }
                     const int vi = butterfly_sum<C::KW>(acc3, lane);
                     if (butterfly_owner<C::KW>(lane)) {
