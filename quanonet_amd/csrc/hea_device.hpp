@@ -1174,9 +1174,16 @@ struct PairSync {
 // already far enough) costs no LDS access at all.
 __device__ __forceinline__ bool pair_wait_ge(int* counter, int target, int* abort_flag, int& seen) {
     if (seen >= target) return true;
+#ifdef QHEA_PROFILE_WAITS   // measurement build (make profile_waits): time spent in hand-off waits, per wave, in ZSync::waited
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long* wt = reinterpret_cast<unsigned long long*>(abort_flag + 5) + 2 * (threadIdx.x >> 6);   // ZSync::waited
+#endif
 #pragma clang loop unroll(disable)              // (the compiler unrolls the spin 8x otherwise: 26 KB of reverse-walk code)
     for (int it = 0; it < kSpinLimit; ++it) {
         seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+#ifdef QHEA_PROFILE_WAITS
+        if (seen >= target && (threadIdx.x & 63) == 0) { wt[0] += __builtin_amdgcn_s_memtime() - t0; wt[1] += 1 + ((unsigned long long)(it > 0) << 32); }
+#endif
         if (seen >= target) return true;
         if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
         __builtin_amdgcn_s_sleep(2);

@@ -164,7 +164,11 @@ constexpr int kSlots = 8, kDist = 6;
 #define QHEA_ZSIGMA 3
 #endif
 constexpr int kZSigma = QHEA_ZSIGMA;
+#ifdef QHEA_PROFILE_WAITS
+struct ZSync { int psi_prod, lam_prod, ready, abort; int cursor[4]; unsigned long long waited[16]; };   // abort + 32 bytes -> waited
+#else
 struct ZSync { int psi_prod, lam_prod, ready, abort; int cursor[kZSigma]; };
+#endif
 constexpr int kRecRingBytes = kSlots * kRecBytes;           // per streaming wave
 
 template <int N>
@@ -1009,6 +1013,10 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
     const int klow = lane & (C::LANES - 1);
     const int E = a.E;
 
+#ifdef QHEA_PROFILE_WAITS
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    if (tid < 16) sync.waited[tid] = 0;
+#endif
     if (tid == 0) {
         sync.psi_prod = 0; sync.lam_prod = 0; sync.ready = 0; sync.abort = 0;
         for (int w = 0; w < kZSigma; ++w) sync.cursor[w] = w;
@@ -1154,6 +1162,11 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
             }
         }
     }
+#ifdef QHEA_PROFILE_WAITS
+    if (blockIdx.x == 100 && lane == 0)
+        printf("role %d: total %llu ticks, in waits %llu ticks, %llu waits that read the counter (%llu of them spun)\n", role,
+               __builtin_amdgcn_s_memtime() - t_begin, sync.waited[2 * wv], sync.waited[2 * wv + 1] & 0xffffffffull, sync.waited[2 * wv + 1] >> 32);
+#endif
     report_abort(&sync.abort, a.status, lane);
     if constexpr (PIPES > 1) {
         __syncthreads();                                   // every wave gets here, also after an overrun
