@@ -140,7 +140,7 @@ __device__ inline LayerInfo decode_layer(const Runs& r, int n, int l) {
 constexpr int kGmapDoubles = 8;
 __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, const double* __restrict__ w,
                                                       char* __restrict__ rec, char* __restrict__ srec,
-                                                      double* __restrict__ gmap, double* __restrict__ emap, WorkspaceHeader* hdr) {
+                                                      double* __restrict__ gmap, WorkspaceHeader* hdr) {
     const int l = blockIdx.x, j = threadIdx.x;
     if (l == 0 && j == 0) header_init(hdr);
     const LayerInfo cur = decode_layer(runs, n, l < L ? l : -1), prev = decode_layer(runs, n, l - 1);
@@ -160,10 +160,13 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
                 // so Im<lam|X_q|psi> there = n . (X, Y, Z)_q here with n the axis of RY RZ X RZ^-1 RY^-1 =
                 // (cos beta cos theta, sin beta, -cos beta sin theta)  (the same for wire 4, whose gate runs as RY between
                 // RZ(+-pi/2): its Y there is that X).
-                const double2 zb = cmul(g.v, g.v);                   // e^{-i beta}
-                const double cb = zb.x, sb = -zb.y, ct = g.c * g.c - g.s * g.s, st = 2.0 * g.c * g.s;
-                double* em = emap + ((long)li.s * n + q) * 4;
-                em[0] = cb * ct; em[1] = sb; em[2] = -cb * st; em[3] = 0.0;
+                // The three numbers ride in the chunk's own record (layer l - 1), whose RY part is otherwise unused.
+                if (prev.kind == 0 && prev.m == n && l >= 1) {
+                    const double2 zb = cmul(g.v, g.v);               // e^{-i beta}
+                    const double cb = zb.x, sb = -zb.y, ct = g.c * g.c - g.s * g.s, st = 2.0 * g.c * g.s;
+                    double* em = reinterpret_cast<double*>(rec + (long)(l - 1) * kRecBytes + kRecRy) + 3 * q;
+                    em[0] = cb * ct; em[1] = sb; em[2] = -cb * st;
+                }
             }
         }
     }
@@ -195,12 +198,13 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
         }
     } else if (j >= 32 && j < 32 + 2 * n) {
         const int q = (j - 32) >> 1, var = (j - 32) & 1;
-        double2 e = make_double2(1.0, 0.0);
-        if (cur.kind == 1) e = make_double2(gz[0][q].c, var ? gz[0][q].s : -gz[0][q].s);
-        *reinterpret_cast<double2*>(out + kRecRy + q * 32 + var * 16) = e;
-        if (srec) {     // wire 4: the swap form's variants (c, -s) / (s, c)
-            if (cur.kind == 1 && q == 4 && var == 1) e = make_double2(gz[0][q].s, gz[0][q].c);
-            *reinterpret_cast<double2*>(srec + (long)l * kRecBytes + kSRecRy + q * 32 + var * 16) = e;
+        if (cur.kind == 1) {    // (an RX chunk's record keeps this part for the next sub-layer's axes, written by ITS block)
+            double2 e = make_double2(gz[0][q].c, var ? gz[0][q].s : -gz[0][q].s);
+            *reinterpret_cast<double2*>(out + kRecRy + q * 32 + var * 16) = e;
+            if (srec) {     // wire 4: the swap form's variants (c, -s) / (s, c)
+                if (q == 4 && var == 1) e = make_double2(gz[0][q].s, gz[0][q].c);
+                *reinterpret_cast<double2*>(srec + (long)l * kRecBytes + kSRecRy + q * 32 + var * 16) = e;
+            }
         }
     }
 }
@@ -367,7 +371,7 @@ int make_shape(int n, int nb, const int32_t* enc, const int32_t* ld, Shape& sh) 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t off_U, off_cs, off_part, off_rec, off_srec, off_gmap, off_emap, total;
+    size_t off_U, off_cs, off_part, off_rec, off_srec, off_gmap, total;
     long nwaves, nwaves_fwd;
     bool lds_fwd, lds_bwd, pair;
     bool zfwd, zfwd_shared, ztri, zpacked;   // ZYZ-form kernels of hea_zyz.hpp (n <= 5): forward (private / shared record ring),
@@ -484,7 +488,6 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     L.off_srec = p; p = align_up(p + (L.zsplit ? (size_t)(L.zL + 1 + 2 * kPadRecs) * kRecBytes : 0));
     if (L.zsplit) L.off_srec += (size_t)kPadRecs * kRecBytes;
     L.off_gmap = p; p = align_up(p + (zok ? (size_t)sh.blk * n * kGmapDoubles * sizeof(double) : 0));
-    L.off_emap = p; p = align_up(p + (zok ? (size_t)sh.blk * n * 4 * sizeof(double) : 0));
     L.total = p;
     return L;
 }
@@ -504,7 +507,7 @@ inline void profile_end(hipStream_t st) {
 int launch_prep_zyz(int n, const Shape& sh, const double* w, char* ws, const Layout& L, hipStream_t st) {
     hipLaunchKernelGGL(prep_zyz_kernel, dim3((unsigned)(L.zL + 1)), dim3(64), 0, st, sh.runs, n, L.zL, w,
                        ws + L.off_rec, L.zsplit ? ws + L.off_srec : nullptr, reinterpret_cast<double*>(ws + L.off_gmap),
-                       reinterpret_cast<double*>(ws + L.off_emap), reinterpret_cast<WorkspaceHeader*>(ws));
+                       reinterpret_cast<WorkspaceHeader*>(ws));
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 int launch_zyz_forward(int n, const Shape& sh, int64_t B, const Layout& L, char* ws, const AngleSrc& src, double off, double co,
@@ -550,8 +553,7 @@ int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char
     const ZBwdArgs za{sh.runs, (long)B, (int)sh.E, (int)sh.blk, ws + L.off_rec, (int)((L.zL + 1) * kRecBytes), L.zL, src, off, co,
                       diag, pauli, g, state_in, y, bias, inv_bt, out, grad_x, partial,
                       &reinterpret_cast<WorkspaceHeader*>(ws)->status, fast, nblocks,
-                      (L.zsplit && !L.zpacked) ? ws + L.off_srec : nullptr, L.zpipes,
-                      reinterpret_cast<const double*>(ws + L.off_emap)};
+                      (L.zsplit && !L.zpacked) ? ws + L.off_srec : nullptr, L.zpipes};
     const size_t dyn = (size_t)(64 >> n) * zyz_cs_row(n, sh.E) * sizeof(double2);
     if (L.zpacked) {
         switch (n) {

@@ -164,10 +164,11 @@ constexpr int kSlots = 8, kDist = 6;
 #define QHEA_ZSIGMA 3
 #endif
 constexpr int kZSigma = QHEA_ZSIGMA;
+constexpr int kAxisRing = 16;                   // blocks whose RX-gradient axes (15 doubles) are kept for the sigma waves: > ring depth / LD
 #ifdef QHEA_PROFILE_WAITS
-struct ZSync { int psi_prod, lam_prod, ready, abort; int cursor[4]; unsigned long long waited[16]; };   // abort + 32 bytes -> waited
+struct ZSync { int psi_prod, lam_prod, ready, abort; int cursor[4]; unsigned long long waited[16]; int next; };   // abort + 20 bytes -> waited
 #else
-struct ZSync { int psi_prod, lam_prod, ready, abort; int cursor[kZSigma]; };
+struct ZSync { int psi_prod, lam_prod, ready, abort; int cursor[kZSigma]; int next; };
 #endif
 constexpr int kRecRingBytes = kSlots * kRecBytes;           // per streaming wave
 
@@ -658,7 +659,6 @@ struct ZBwdArgs {
     int fast_ld, nblocks;
     const char* srec;           // split records for the forward phase, nullptr: all-lane forward sweep
     int pipes;                  // bwd_ztri_kernel: sample groups per workgroup (1 or 2)
-    const double* emap;         // per ansatz gate 4 doubles: axis that maps its (X, Y, Z) sums to the preceding RX gate's gradient
 };
 
 // kWaves sweeping waves + kFwdHelpers waves that only help to fill the (cos, sin) tables and then leave: the fill is
@@ -761,7 +761,7 @@ __global__ __launch_bounds__((kSplitWaves + kSplitHelpers) * 64) void fwd_split_
 template <int N, int MODE, bool SPLIT, int RING>
 __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane, int klow, bool valid, long b,
                                            const double2* cs, char* my_ring, double2 (*psi_ring)[64],
-                                           double2 (*lam_ring)[64], double2* psi_final, ZSync* sync) {
+                                           double2 (*lam_ring)[64], double2* psi_final, ZSync* sync, double* axis_ring) {
     using C = Cfg<N>;
     static_assert(!SPLIT || (N == 5 && MODE != 0), "split layout: n = 5, block-unrolled shapes");
     __builtin_amdgcn_s_setprio(3);                          // the chains are the critical path (hea_device.hpp)
@@ -872,6 +872,10 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
         auto block = [&](auto sl, int bl, int kb) {
             const char* cur = bs.template slot_rel<0>(sl);
             const char* nx = bs.template slot_rel<-1>(sl);
+            // the axes that turn this block's first sub-layer's (X, Y, Z) into its RX chunk's gradients ride in the chunk's
+            // record (prep_zyz_kernel); the lambda wave leaves them where the sigma waves find them, before it publishes
+            // the block's first step
+            if (role == 1 && lane < 3 * N) axis_ring[(bl & (kAxisRing - 1)) * (3 * N) + lane] = reinterpret_cast<const double*>(cur + kRecRy)[lane];
             // ---- last sub-layer: ring^-1, publish, RY^-1, then the diagonal in front of it
             if constexpr (LD == 2) read_layer(cm, cur, 1);
             else read_chunk(cur, cs_b - kb * (N * CW));
@@ -978,7 +982,9 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
 // partial rows for the reduce kernel to read.  Chosen when two workgroups would share a CU anyway (hea_api.hip).
 constexpr int kZPipeWaves = 2 + kZSigma;
 // LDS of one pipeline apart from its (cos, sin) table: two record rings, psi and lambda hand-off rings, psi_N, counters
-__host__ __device__ constexpr size_t ztri_fixed_lds(int ring) { return 2 * (size_t)kBlockRingBytes + 2 * (size_t)ring * 1024 + 1024 + 64; }
+__host__ __device__ constexpr size_t ztri_fixed_lds(int ring) {
+    return 2 * (size_t)kBlockRingBytes + 2 * (size_t)ring * 1024 + 1024 + 256 + (size_t)kAxisRing * 15 * sizeof(double);
+}
 template <int PIPES>
 __device__ __forceinline__ int pipe_of_wave() {
     return PIPES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) / kZPipeWaves;
@@ -1006,6 +1012,8 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
     double2 (*lam_ring)[64] = reinterpret_cast<double2 (*)[64]>(fixed + 2 * kBlockRingBytes + RING * 1024);
     double2* psi_final = reinterpret_cast<double2*>(fixed + 2 * kBlockRingBytes + 2 * RING * 1024);
     ZSync& sync = *reinterpret_cast<ZSync*>(fixed + 2 * kBlockRingBytes + 2 * RING * 1024 + 1024);
+    static_assert(sizeof(ZSync) <= 256, "reserved");
+    double* axis_ring = reinterpret_cast<double*>(fixed + 2 * kBlockRingBytes + 2 * RING * 1024 + 1024 + 256);
     const long wave = (long)blockIdx.x * PIPES + pipe;                            // one sample group per pipeline; a group past
     const long b_raw = wave * C::SPW + (lane >> C::LB);                           // the batch runs on copies of the last sample
     const bool valid = b_raw < a.B;                                               // with lambda = 0
@@ -1017,9 +1025,11 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     if (tid < 16) sync.waited[tid] = 0;
 #endif
+    const bool split_steps = a.fast_ld != 0;              // sigma waves draw their steps from a counter (below)
     if (tid == 0) {
         sync.psi_prod = 0; sync.lam_prod = 0; sync.ready = 0; sync.abort = 0;
-        for (int w = 0; w < kZSigma; ++w) sync.cursor[w] = w;
+        for (int w = 0; w < kZSigma; ++w) sync.cursor[w] = split_steps ? 0 : w;
+        sync.next = 0;
     }
     const bool split = N == 5 && a.srec != nullptr && a.fast_ld != 0;
     const int cs_bytes = (int)(C::SPW * zyz_cs_row(N, E) * (split ? 32 : 16));
@@ -1040,125 +1050,148 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
         bool done = false;
         if constexpr (N == 5) {
             if (split) {
-                if (a.fast_ld == 2) ztri_chain<N, 2, true, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
-                else ztri_chain<N, 1, true, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+                if (a.fast_ld == 2) ztri_chain<N, 2, true, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync, axis_ring);
+                else ztri_chain<N, 1, true, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync, axis_ring);
                 done = true;
             }
         }
         if (done) {}
-        else if (a.fast_ld == 2) ztri_chain<N, 2, false, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
-        else if (a.fast_ld == 1) ztri_chain<N, 1, false, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
-        else ztri_chain<N, 0, false, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync);
+        else if (a.fast_ld == 2) ztri_chain<N, 2, false, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync, axis_ring);
+        else if (a.fast_ld == 1) ztri_chain<N, 1, false, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync, axis_ring);
+        else ztri_chain<N, 0, false, RING>(a, role, lane, klow, valid, b, cs, my_ring, psi_ring, lam_ring, psi_final, &sync, axis_ring);
     } else {
         // ------------------------------------------------------------------ sigma waves: inner products + sums
         double* __restrict__ part_w = a.partial + wave * (long)a.blk * C::KW;       // PIPES = 1: this group's row
         const int me = role - 2;
         int seen_p = 0, seen_l = 0;
-        int col = E, sub = a.blk, step = 0;
-        // Block-unrolled shapes (every block: one full RX chunk + LD sub-layers): the chains do not publish at the RX chunk.
-        // With psi_C = W psi_E, lambda_C = W lambda_E, W = prod_q RY(theta_q) RZ(beta_q) the layer between the chunk (E) and
-        // the block's first sub-layer's publication point (C):  Im<lam_E|X_q|psi_E> = n_q . (X, Y, Z)_q at C, n_q batch
-        // invariant (prep_zyz_kernel, `emap`) -- so the chunk's gradients are a per-lane combination of the products this
-        // sub-layer forms anyway, summed per sample: one pipeline step and two publications less per block.
-        const bool merged = a.fast_ld != 0;
-        // Which sigma wave takes step t.  Plain alternation, except for merged blocks of two sub-layers: there every second
-        // step carries the chunk's gradients as well, and with an even number of sigma waves plain rotation would hand all of
-        // those to the same waves -- the owner (t + t/2) mod kZSigma (0 1 1 0 | 0 1 1 0 ... for two waves) rotates them too.
-        static_assert(kZSigma >= 2 && kZSigma <= 4, "owner pattern and coefficient prefetch below");
-        const bool skew = merged && a.fast_ld == 2 && kZSigma % 2 == 0;
-        auto owner = [&](int t) { return skew ? (t + (t >> 1)) % kZSigma : t % kZSigma; };
-        auto next_owned = [&](int t) { int u = t + 1; while (owner(u) != me) ++u; return u; };   // at most kZSigma + 1 tries
-        // Either way a wave owns the chunk-carrying step of every kZSigma-th block, so it fetches the axis coefficients of its
-        // next such block right after it has used the current ones: a fetch at the point of use would put a global round
-        // trip into the step (measured: +5 us per launch).
-        double em[3 * N];
-        auto load_em = [&](int sub0) {                     // sub-layer sub0's gates; wave-uniform address
-            const double* __restrict__ e = a.emap + (long)(sub0 < 0 ? 0 : sub0) * N * 4;
+        // the X, Y, Z terms of this lane for every qubit, from psi (own p, partners qv) and lambda of one published step
+        auto products = [&](double (&acc3)[C::KW], const double2& p, const double2 (&qv)[N], const double2& lm) {
+#pragma unroll
+            for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
             static_for<0, N>([&](auto q) {
                 constexpr int Q = decltype(q)::value;
-                em[3 * Q] = e[4 * Q]; em[3 * Q + 1] = e[4 * Q + 1]; em[3 * Q + 2] = e[4 * Q + 2];
+                const double sg = ((lane >> Q) & 1) ? -1.0 : 1.0;
+                acc3[3 * Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
+                acc3[3 * Q + 1] = -sg * (lm.x * qv[Q].x + lm.y * qv[Q].y);
+                acc3[3 * Q + 2] = sg * (lm.x * p.y - lm.y * p.x);
             });
         };
-        if (merged) {
-            int j0 = 0;                                        // first block (in walking order) whose chunk-carrying step is mine
-            while (owner(j0 * a.fast_ld + a.fast_ld - 1) != me) ++j0;
-            load_em(a.blk - (j0 + 1) * a.fast_ld);
-        }
-        for (int ri = a.runs.nruns - 1; ri >= 0; --ri) {
-            const int ne = a.runs.enc[ri], nld = a.runs.ld[ri];
-            const int nch = (ne + N - 1) / N;
-            const int m_last = ne - (nch - 1) * N;
-            for (int rep = 0; rep < a.runs.count[ri]; ++rep) {
-                for (int s = nld - 1; s >= 0; --s) {
-                    --sub;
-                    if (owner(step) != me) { ++step; continue; }
-                    pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
-                    pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
-                    const double2* slot = psi_ring[step & (RING - 1)];
-                    const double2 p = slot[lane];
-                    double2 qv[N];
-                    static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
-                    const double2 lm = lam_ring[step & (RING - 1)][lane];
-                    __hip_atomic_store(&sync.cursor[me], next_owned(step), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    ++step;
-                    double acc3[C::KW];
+        auto store_sums = [&](double (&acc3)[C::KW], int sub) {
+            const int vi = butterfly_sum<C::KW>(acc3, lane);
+            if (butterfly_owner<C::KW>(lane)) {
+                if constexpr (PIPES == 1) part_w[(long)sub * C::KW + vi] = acc3[0];
+                else __hip_atomic_fetch_add(&row_lds[sub * C::KW + vi], acc3[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        if (split_steps) {
+            // Block-unrolled shapes (every block: one full RX chunk + LD sub-layers).
+            //  * The chains do not publish at the RX chunk.  With psi_C = W psi_E, lambda_C = W lambda_E, W = prod_q RY(theta_q)
+            //    RZ(beta_q) the layer between the chunk (E) and the block's first sub-layer's publication point (C):
+            //    Im<lam_E|X_q|psi_E> = n_q . (X, Y, Z)_q at C with n_q batch invariant (prep_zyz_kernel; handed over by the
+            //    lambda wave in `axis_ring`) -- the chunk's gradients are a per-lane combination of the products that sub-layer's
+            //    step forms anyway, summed per sample: one pipeline step and two publications less per block.
+            //  * The sigma waves DRAW their steps from a counter instead of owning every kZSigma-th one: the waves of a
+            //    workgroup do not run equally fast (the fifth shares its SIMD with a chain wave, steps with a chunk are heavier),
+            //    and the slowest sigma wave is the kernel's tail.  A wave holds its current step and the next one (`after`, drawn
+            //    early so that the counter's latency is off its path); cursor[me] = the step it will read next, as before.
+            const int LDr = a.fast_ld, nsteps = a.nblocks * LDr;
+            auto draw = [&]() {                                // valid in lane 0
+                int v = 0;
+                if (lane == 0) v = __hip_atomic_fetch_add(&sync.next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return v;
+            };
+            int mine = __builtin_amdgcn_readfirstlane(draw());
+            int after_v = draw();
+            while (mine < nsteps) {
+                const int t = mine;
+                const int j = LDr == 2 ? (t >> 1) : t;         // block, in walking order
+                const bool chunk = LDr == 2 ? (t & 1) : true;  // the block's first sub-layer (its last step)
+                const int sub = a.blk - 1 - t, bl = a.nblocks - 1 - j;
+                pair_wait_ge(&sync.psi_prod, t + 1, &sync.abort, seen_p);
+                pair_wait_ge(&sync.lam_prod, t + 1, &sync.abort, seen_l);
+                const double2* slot = psi_ring[t & (RING - 1)];
+                const double2 p = slot[lane];
+                double2 qv[N];
+                static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
+                const double2 lm = lam_ring[t & (RING - 1)][lane];
+                double em[3 * N];
+                if (chunk) {
+                    const double* __restrict__ e = axis_ring + (bl & (kAxisRing - 1)) * (3 * N);
 #pragma unroll
-                    for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
-                    static_for<0, N>([&](auto q) {
-                        constexpr int Q = decltype(q)::value;
-                        const double sg = ((lane >> Q) & 1) ? -1.0 : 1.0;
-                        acc3[3 * Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
-                        acc3[3 * Q + 1] = -sg * (lm.x * qv[Q].x + lm.y * qv[Q].y);
-                        acc3[3 * Q + 2] = sg * (lm.x * p.y - lm.y * p.x);
-                    });
-                    double gx[C::KX];
-                    if (merged && s == 0) {
-#pragma unroll
-                        for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
-                        static_for<0, N>([&](auto q) {
-                            constexpr int Q = decltype(q)::value;
-                            gx[Q] = em[3 * Q] * acc3[3 * Q] + em[3 * Q + 1] * acc3[3 * Q + 1] + em[3 * Q + 2] * acc3[3 * Q + 2];
-                        });
-                        load_em(sub - kZSigma * nld);         // this wave's next chunk-carrying step
-                    }
-                    const int vi = butterfly_sum<C::KW>(acc3, lane);
-                    if (butterfly_owner<C::KW>(lane)) {
-                        if constexpr (PIPES == 1) part_w[(long)sub * C::KW + vi] = acc3[0];
-                        else __hip_atomic_fetch_add(&row_lds[sub * C::KW + vi], acc3[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    if (merged && s == 0) {
-                        if constexpr (N == 5) store_grad_x5(gx, lane, wave, a.B, E, a.grad_x, col - ne, N);
-                        else store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, col - ne, N);
-                    }
+                    for (int i = 0; i < 3 * N; ++i) em[i] = e[i];
                 }
-                for (int ch = nch - 1; ch >= 0; --ch) {
-                    if (merged) continue;                     // (its gradients came with sub-layer 0 above)
-                    const int m = ch == nch - 1 ? m_last : N;
-                    if (owner(step) != me) { ++step; continue; }
-                    pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
-                    pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
-                    const double2* slot = psi_ring[step & (RING - 1)];
-                    double2 qv[N];
-                    static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
-                    const double2 lm = lam_ring[step & (RING - 1)][lane];
-                    __hip_atomic_store(&sync.cursor[me], next_owned(step), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    ++step;
-                    double gx[C::KX];
+                if (lane == 0) __hip_atomic_store(&sync.cursor[me], after_v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                mine = __builtin_amdgcn_readfirstlane(after_v);
+                after_v = draw();
+                double acc3[C::KW];
+                products(acc3, p, qv, lm);
+                double gx[C::KX];
+                if (chunk) {
 #pragma unroll
                     for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
-                    for_gates_below<N>(m, [&](auto q) {
+                    static_for<0, N>([&](auto q) {
                         constexpr int Q = decltype(q)::value;
-                        if constexpr (Q == 4) {           // this wire's encoding gate runs as RY (apply_enc): Y inner product
-                            const double sg = ((lane >> Q) & 1) ? -1.0 : 1.0;
-                            gx[Q] = -sg * (lm.x * qv[Q].x + lm.y * qv[Q].y);
-                        } else {
-                            gx[Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
-                        }
+                        gx[Q] = em[3 * Q] * acc3[3 * Q] + em[3 * Q + 1] * acc3[3 * Q + 1] + em[3 * Q + 2] * acc3[3 * Q + 2];
                     });
-                    if constexpr (N == 5) store_grad_x5(gx, lane, wave, a.B, E, a.grad_x, col - ne + ch * N, m);
-                    else store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, col - ne + ch * N, m);
                 }
-                col -= ne;
+                store_sums(acc3, sub);
+                if (chunk) {
+                    if constexpr (N == 5) store_grad_x5(gx, lane, wave, a.B, E, a.grad_x, bl * N, N);
+                    else store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, bl * N, N);
+                }
+            }
+        } else {
+            // other shapes: the chains publish at every layer, sigma wave w takes the steps t = w (mod kZSigma)
+            int col = E, sub = a.blk, step = 0;
+            for (int ri = a.runs.nruns - 1; ri >= 0; --ri) {
+                const int ne = a.runs.enc[ri], nld = a.runs.ld[ri];
+                const int nch = (ne + N - 1) / N;
+                const int m_last = ne - (nch - 1) * N;
+                for (int rep = 0; rep < a.runs.count[ri]; ++rep) {
+                    for (int s = nld - 1; s >= 0; --s) {
+                        --sub;
+                        if (step % kZSigma != me) { ++step; continue; }
+                        pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
+                        pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
+                        const double2* slot = psi_ring[step & (RING - 1)];
+                        const double2 p = slot[lane];
+                        double2 qv[N];
+                        static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
+                        const double2 lm = lam_ring[step & (RING - 1)][lane];
+                        __hip_atomic_store(&sync.cursor[me], step + kZSigma, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        ++step;
+                        double acc3[C::KW];
+                        products(acc3, p, qv, lm);
+                        store_sums(acc3, sub);
+                    }
+                    for (int ch = nch - 1; ch >= 0; --ch) {
+                        const int m = ch == nch - 1 ? m_last : N;
+                        if (step % kZSigma != me) { ++step; continue; }
+                        pair_wait_ge(&sync.psi_prod, step + 1, &sync.abort, seen_p);
+                        pair_wait_ge(&sync.lam_prod, step + 1, &sync.abort, seen_l);
+                        const double2* slot = psi_ring[step & (RING - 1)];
+                        double2 qv[N];
+                        static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
+                        const double2 lm = lam_ring[step & (RING - 1)][lane];
+                        __hip_atomic_store(&sync.cursor[me], step + kZSigma, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        ++step;
+                        double gx[C::KX];
+#pragma unroll
+                        for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
+                        for_gates_below<N>(m, [&](auto q) {
+                            constexpr int Q = decltype(q)::value;
+                            if constexpr (Q == 4) {           // this wire's encoding gate runs as RY (apply_enc): Y inner product
+                                const double sg = ((lane >> Q) & 1) ? -1.0 : 1.0;
+                                gx[Q] = -sg * (lm.x * qv[Q].x + lm.y * qv[Q].y);
+                            } else {
+                                gx[Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
+                            }
+                        });
+                        if constexpr (N == 5) store_grad_x5(gx, lane, wave, a.B, E, a.grad_x, col - ne + ch * N, m);
+                        else store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, col - ne + ch * N, m);
+                    }
+                    col -= ne;
+                }
             }
         }
     }
