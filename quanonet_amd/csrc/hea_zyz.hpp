@@ -159,7 +159,8 @@ constexpr int kSlots = 8, kDist = 6;
 // their first step, the chains do wait for ring slots: DESIGN.md 3.4), so a third one pays -- once two 5-wave workgroups fit
 // a CU, which takes <= 128 VGPRs (four wave slots per SIMD; the kernel's LDS is all dynamic so that the compiler does not cap
 // its occupancy estimate at the LDS limit, and the walks keep one layer's coefficients ahead instead of a block's).
-// cfg 2, us per launch with 2 / 3 / 4 sigma waves: B = 512 78.5 / 72.1 / 70.8, B = 1024 98.7 / 92.0 / 96.8, B = 1536 159 / 143 / 166.
+// cfg 2, us per launch with 2 / 3 / 4 sigma waves (steps drawn from a counter): B = 512 74.0 / 70.2 / 72.3, B = 1024 94.6 / 90.4 / 92.1,
+// B = 1536 149 / 141 / 158.
 #ifndef QHEA_ZSIGMA
 #define QHEA_ZSIGMA 3
 #endif
