@@ -77,11 +77,9 @@ __device__ __forceinline__ double2 cmul(const double2& a, const double2& b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 __device__ __forceinline__ double2 cconj(const double2& a) { return make_double2(a.x, -a.y); }
-__device__ inline GateZ gate_zyz(const double* __restrict__ ws /* w + s*3*n */, int n, int q) {
-    double sa, ca, sb, cb, sc, cc;
-    sincos(0.5 * ws[q], &sa, &ca);
-    sincos(0.5 * ws[n + q], &sb, &cb);
-    sincos(0.5 * ws[2 * n + q], &sc, &cc);
+// (cos, sin) of the three HALF angles a/2, b/2, c/2 of the gate, computed by three threads (prep_zyz_kernel)
+__device__ inline GateZ gate_zyz(const double2& ha, const double2& hb, const double2& hc) {
+    const double ca = ha.x, sa = ha.y, cb = hb.x, sb = hb.y, cc = hc.x, sc = hc.y;
     const double m00r = cb * ca, m00i = -sb * ca, m01r = -cb * sa, m01i = sb * sa;
     const double m10r = cb * sa, m10i = sb * sa, m11r = cb * ca, m11i = sb * ca;
     const double Ar = cc * m00r - sc * m10r, Ai = cc * m00i - sc * m10i;
@@ -145,11 +143,22 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
     if (l == 0 && j == 0) header_init(hdr);
     const LayerInfo cur = decode_layer(runs, n, l < L ? l : -1), prev = decode_layer(runs, n, l - 1);
     __shared__ GateZ gz[2][QHEA_MAX_QUBITS];           // [0]: this layer's gates, [1]: the previous layer's
+    __shared__ double2 half[2][3][QHEA_MAX_QUBITS];    // (cos, sin) of the half angles: one sincos per thread, not three in a row
+    if (j < 6 * n) {
+        const int which = j / (3 * n), k = (j / n) % 3, q = j % n;
+        const LayerInfo& li = which ? prev : cur;
+        if (li.kind == 1) {
+            double sn, cn;
+            sincos(0.5 * w[(long)li.s * 3 * n + k * n + q], &sn, &cn);
+            half[which][k][q] = make_double2(cn, sn);
+        }
+    }
+    __syncthreads();
     if (j < 2 * n) {                                   // one decomposition per thread, then everybody multiplies phasors
         const int which = j / n, q = j % n;
         const LayerInfo& li = which ? prev : cur;
         if (li.kind == 1) {
-            const GateZ g = gate_zyz(w + (long)li.s * 3 * n, n, q);
+            const GateZ g = gate_zyz(half[which][0][q], half[which][1][q], half[which][2][q]);
             gz[which][q] = g;
             if (which == 0) {
                 const double2 z = cmul(g.u, g.u);                    // e^{-i alpha}
