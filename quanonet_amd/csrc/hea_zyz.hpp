@@ -18,13 +18,18 @@
 // Gradients: the inner products X, Y, Z = Im<lambda|sigma_q|psi> are taken after the RY layer (position C, before
 // the ring), where the true state is D_post psi_C with D_post = prod_q RZ(alpha_q); sigma_q conjugated by RZ(alpha_q)
 // is a rotation of (X, Y) by alpha_q about Z, batch invariant, applied once per call in the reduce kernel
-// (reduce_xyz_block, zyz = true) before the usual 3x3 map to the three angle gradients.  RX gradients are unchanged.
+// (reduce_xyz_block, zyz = true) before the usual 3x3 map to the three angle gradients.  RX gradients: the X (wire 4: Y)
+// inner product right after the chunk in the generic walk and the one-wave kernel; in the pipeline kernel's block walk
+// they are read off the NEXT sub-layer's X, Y, Z through a batch-invariant axis (bwd_ztri_kernel, sigma waves).
 // Verified first in numpy against the oracle (1e-15, scripts/exp/zyz_prototype.py), then by the parity tests.
 //
 // Layer records (built by prep_zyz_kernel, hea_api.hip): one 1 KB record per layer in circuit order, a layer being
 // one RX chunk (<= n encodings) or one ansatz sub-layer, plus a final record:
 //   bytes [0, 16 * 2^n)          e^{i Phi_l(k)} as (cos, sin) for basis index k: the diagonal applied BEFORE layer l
 //   bytes [512, 512 + 32 n)      ansatz layers: (cos(theta_q/2), -/+ sin(theta_q/2)) for lane-bit 0 / 1 of qubit q
+//                                full RX chunks: 3 n doubles, the axes n_q of the following sub-layer's gates (see above)
+// Kernels: fwd_zyz_kernel / fwd_split_kernel / fwd_zshared_kernel (forward; private ring / split layout / shared ring),
+// bwd_ztri_kernel (psi / lambda / sigma pipeline, small batches), bwd_zpacked_kernel (one wave per group, large batches).
 // Reference: same circuit as hea_device.hpp (core/quantum_circuits_tq.py:65-127).
 #pragma once
 #include "hea_device.hpp"
