@@ -192,6 +192,29 @@ def test_two_pipelines_per_workgroup(dev, ld):
         _lib.check_status(dev)
 
 
+@pytest.mark.parametrize('B', [513, 640, 1100, 1537, 2100])
+def test_auto_dispatch_across_batch_regimes(dev, B):
+    """n = 5, block-unrolled shape, default (AUTO) dispatch at the batch sizes where it changes kernels or occupancy:
+    one pipeline workgroup per CU (<= 512), two per CU (513 ... 1024), a third that LDS does not admit (... 1536), the
+    one-wave ZYZ kernel beyond; odd batches leave a half-filled last sample group.  Forward through the split-layout
+    kernel up to one sample per SIMD, the all-lane kernels beyond."""
+    n, cfgs = 5, [(5, 2)] * 3
+    rng = np.random.default_rng(9000 + B)
+    E, blk = O.circuit_sizes(n, cfgs)
+    x = rng.uniform(-np.pi, np.pi, (B, E))
+    w = rng.uniform(-np.pi, np.pi, (blk, 3, n))
+    g = rng.normal(size=B)
+    off, co = O.ham_params(n, -2.0, 5.0)
+    ro, rgx, rgw = C.hea_backward(n, cfgs, x, w, g, off, co)
+    out, st, gx, gw, out2 = _run(n, cfgs, x, w, g, dev, off, co, use_state=False)
+    np.testing.assert_allclose(out, ro, rtol=0, atol=TOL)
+    np.testing.assert_allclose(out2, ro, rtol=0, atol=TOL)
+    np.testing.assert_allclose(gx, rgx, rtol=0, atol=TOL)
+    np.testing.assert_allclose(gw, rgw, rtol=0, atol=1e-9)          # sums over up to 2100 samples
+    from quanonet_amd import _lib
+    _lib.check_status(dev)
+
+
 def test_ham_diag_readout(dev):
     n, cfgs = 4, [(4, 1), (4, 2)]
     rng = np.random.default_rng(7)
