@@ -205,11 +205,11 @@ __device__ __forceinline__ void lane_reduce(double (&v)[K], int lane) {
 //   bits 3, 2: two bank-masked DPP moves per 32-bit word (row_shr / row_shl by 8 or 4 into the lanes whose bit is 1 / 0,
 //          the other lanes keep the old value) build (own A | partner's B) and (partner's A | own B): 4 moves + 1 add.
 // So the steps with many pairs go to bits 4 and 5: 16 values cost 8*3 + 4*3 + 2*5 + 1*5 + 2*3 = 57 instructions
-// instead of 111.  Returns the index of the value whose 64-lane total this lane holds in v[0]; lanes whose remaining
+// instead of 111, 32 values (n = 6...9) 16*3 + 8*3 + 4*5 + 2*5 + 7 + 3 = 112 instead of 220.  Returns the index of the value whose 64-lane total this lane holds in v[0]; lanes whose remaining
 // low bits are zero are the ones that should store it (`butterfly_owner`).
 template <int K>
 __device__ __forceinline__ int butterfly_sum(double (&v)[K], int lane) {
-    static_assert(K == 8 || K == 16, "K");
+    static_assert(K == 8 || K == 16 || K == 32, "K");
     auto swap_level = [&](int c, auto which) {              // c live values -> c/2; bit 4 (which = 16) or bit 5 (32)
 #pragma unroll
         for (int i = 0; i < K / 2; ++i) {
@@ -240,23 +240,41 @@ __device__ __forceinline__ int butterfly_sum(double (&v)[K], int lane) {
         v[i] = __hiloint2double(a2hi, a2lo) + __hiloint2double(b2hi, b2lo);
     }
     int idx = ((lane >> 4) & 1) | (((lane >> 5) & 1) << 1) | (((lane >> 3) & 1) << 2);
-    if constexpr (K == 16) {
+    if constexpr (K >= 16) {
         // bit 2 (xor 4): row_shr:4 = 0x114 into banks 1,3; row_shl:4 = 0x104 into banks 0,2
-        const int alo = __double2loint(v[0]), ahi = __double2hiint(v[0]);
-        const int blo = __double2loint(v[1]), bhi = __double2hiint(v[1]);
-        const int a2lo = __builtin_amdgcn_update_dpp(alo, blo, 0x114, 0xF, 0xA, false), a2hi = __builtin_amdgcn_update_dpp(ahi, bhi, 0x114, 0xF, 0xA, false);
-        const int b2lo = __builtin_amdgcn_update_dpp(blo, alo, 0x104, 0xF, 0x5, false), b2hi = __builtin_amdgcn_update_dpp(bhi, ahi, 0x104, 0xF, 0x5, false);
-        v[0] = __hiloint2double(a2hi, a2lo) + __hiloint2double(b2hi, b2lo);
+#pragma unroll
+        for (int i = 0; i < K / 16; ++i) {
+            const int alo = __double2loint(v[2 * i]), ahi = __double2hiint(v[2 * i]);
+            const int blo = __double2loint(v[2 * i + 1]), bhi = __double2hiint(v[2 * i + 1]);
+            const int a2lo = __builtin_amdgcn_update_dpp(alo, blo, 0x114, 0xF, 0xA, false), a2hi = __builtin_amdgcn_update_dpp(ahi, bhi, 0x114, 0xF, 0xA, false);
+            const int b2lo = __builtin_amdgcn_update_dpp(blo, alo, 0x104, 0xF, 0x5, false), b2hi = __builtin_amdgcn_update_dpp(bhi, ahi, 0x104, 0xF, 0x5, false);
+            v[i] = __hiloint2double(a2hi, a2lo) + __hiloint2double(b2hi, b2lo);
+        }
         idx |= ((lane >> 2) & 1) << 3;
     } else {
         v[0] = pair_sum<4>(v[0]);
     }
-    v[0] = pair_sum<2>(v[0]);
+    if constexpr (K >= 32) {                                  // bit 1: one pair left, select + quad exchange (7 instructions)
+        const bool up = (lane >> 1) & 1;
+        const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+        v[0] = keep + xchg<2>(send);
+        idx |= ((lane >> 1) & 1) << 4;
+    } else {
+        v[0] = pair_sum<2>(v[0]);
+    }
     v[0] = pair_sum<1>(v[0]);
     return idx;
 }
 template <int K>
-__device__ __forceinline__ bool butterfly_owner(int lane) { return (lane & (K == 16 ? 3 : 7)) == 0; }
+__device__ __forceinline__ bool butterfly_owner(int lane) { return (lane & (K == 32 ? 1 : (K == 16 ? 3 : 7))) == 0; }
+// lane that holds value v after butterfly_sum<K> (the owner among those that do)
+template <int K>
+__device__ __forceinline__ int butterfly_lane_of(int v) {
+    int l = ((v & 1) << 4) | (((v >> 1) & 1) << 5) | (((v >> 2) & 1) << 3);
+    if constexpr (K >= 16) l |= ((v >> 3) & 1) << 2;
+    if constexpr (K >= 32) l |= ((v >> 4) & 1) << 1;
+    return l;
+}
 
 // Sums through a wave-private LDS scratch (rows of kRedStride doubles, one row per value, one column
 // per lane).  Far fewer vector-ALU instructions than the register butterfly: K stores, K/2 wide loads,
@@ -1054,13 +1072,14 @@ __global__ __launch_bounds__(kWaves * 64, MINW) void bwd_kernel(Runs runs, long 
                 if constexpr (C::LDSRED) {
                     sums.put_w(acc3, sub);
                 } else {
-                    lane_reduce<C::KW, 6>(acc3, lane);               // lane i holds the sample's total of value i
-                    if (lane < C::KW) part_w[(long)sub * C::KW + lane] = acc3[0];
+                    const int vi = butterfly_sum<C::KW>(acc3, lane);   // the sample's total of value vi (cheapest lane-bit order)
+                    if (butterfly_owner<C::KW>(lane)) part_w[(long)sub * C::KW + vi] = acc3[0];
                     if constexpr (kFold<N>) {
                         if (folded) {                                // encoding gradients of the folded chunk: n . (X,Y,Z)
-                            const double Y = __shfl_down(acc3[0], 1), Z = __shfl_down(acc3[0], 2);
-                            const int q = lane / 3;
-                            if (lane % 3 == 0 && q < m0 && valid) {
+                            const int q = vi / 3;                    // the lane holding X_q fetches Y_q and Z_q
+                            const double Y = __shfl(acc3[0], butterfly_lane_of<C::KW>(vi + 1 < C::KW ? vi + 1 : vi));
+                            const double Z = __shfl(acc3[0], butterfly_lane_of<C::KW>(vi + 2 < C::KW ? vi + 2 : vi));
+                            if (butterfly_owner<C::KW>(lane) && vi % 3 == 0 && q < m0 && valid) {
                                 const double4 ub = *reinterpret_cast<const double4*>(gates + ((long)(sub + 1) * N + q) * kGateBytes);
                                 double nx, ny, nz;
                                 rotated_x_axis(ub, nx, ny, nz);
@@ -1571,8 +1590,8 @@ __global__ __launch_bounds__(128 + 64 * kSigmaWaves) void bwd_tri_kernel(Runs ru
                         acc3[3 * Q + 1] = -s * (lm.x * qv[Q].x + lm.y * qv[Q].y);
                         acc3[3 * Q + 2] = s * (lm.x * p.y - lm.y * p.x);
                     });
-                    lane_reduce<C::KW, 6>(acc3, lane);                   // registers only: the LDS pipe stays with the chains
-                    if (lane < C::KW) part_w[(long)sub * C::KW + lane] = acc3[0];
+                    const int vi = butterfly_sum<C::KW>(acc3, lane);     // registers only: the LDS pipe stays with the chains
+                    if (butterfly_owner<C::KW>(lane)) part_w[(long)sub * C::KW + vi] = acc3[0];
                 }
                 col -= ne;
                 if (ne > 0 && step % kSigmaWaves != me) {
