@@ -342,11 +342,57 @@ __device__ __forceinline__ double sample_sum_finish(double (&t)[K]) {
 // SU(2) gate [[a,b],[-conj b, conj a]] on qubit Q.  Coefficients come from the gate table already
 // specialised for this lane: u = (ar, s*ai, s*br, bi) with s = +1 when the lane's bit Q is 0 and -1
 // when it is 1 (for a register qubit s = +1).  The adjoint is the same call with (x,-y,-z,-w).
+// Lane qubits 4 and 5 are out of DPP's reach (ds_swizzle / ds_bpermute: the CU's one LDS pipe and 50-60 clocks on the
+// chain).  With two or more amplitudes per lane (n >= 7) the pair a gate on such a qubit mixes can be brought INTO one lane
+// instead: v_permlane16/32_swap(re[r], re[r|1]) leaves (amplitude r of the bit-0 lane, amplitude r of the bit-1 lane) in
+// the even rows / lower half and the same for amplitude r|1 in the odd rows / upper half -- every lane then holds complete
+// pairs in (v[r], v[r|1]), the gate is the in-lane update of a register qubit with the UNSIGNED coefficients (gate-table
+// variant 0 for every lane), and the same swaps put the results back.  The inner products of the backward pass are taken
+// in that frame too (su2_inverse_with_inner), so they need no exchange of their own.
+template <int N, int Q>
+constexpr bool kSwapQubit = (Q >= 4) && (Q < Cfg<N>::LB) && (Cfg<N>::R >= 2);
+template <int N, int Q>
+__device__ __forceinline__ void swap_frame(double (&re)[Cfg<N>::R], double (&im)[Cfg<N>::R]) {
+    auto sw = [](double& a, double& b) {
+        const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+        const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+        if constexpr (Q == 4) {
+            const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+            const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+            a = __hiloint2double((int)hi[0], (int)lo[0]); b = __hiloint2double((int)hi[1], (int)lo[1]);
+        } else {
+            const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+            const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+            a = __hiloint2double((int)hi[0], (int)lo[0]); b = __hiloint2double((int)hi[1], (int)lo[1]);
+        }
+    };
+#pragma unroll
+    for (int r0 = 0; r0 < Cfg<N>::R; r0 += 2) { sw(re[r0], re[r0 + 1]); sw(im[r0], im[r0 + 1]); }
+}
+// [[a, b], [-conj b, conj a]] on the in-lane pairs (r0, r0 | J)
+template <int N, int J>
+__device__ __forceinline__ void su2_in_lane(double (&re)[Cfg<N>::R], double (&im)[Cfg<N>::R], double ar, double ai, double br, double bi) {
+#pragma unroll
+    for (int r0 = 0; r0 < Cfg<N>::R; ++r0) {
+        if (r0 & J) continue;
+        const int r1 = r0 | J;
+        const double p0r = re[r0], p0i = im[r0], p1r = re[r1], p1i = im[r1];
+        re[r0] = ar * p0r - ai * p0i + br * p1r - bi * p1i;
+        im[r0] = ar * p0i + ai * p0r + br * p1i + bi * p1r;
+        re[r1] = ar * p1r + ai * p1i - br * p0r - bi * p0i;     // conj(a) p1 - conj(b) p0
+        im[r1] = ar * p1i - ai * p1r - br * p0i + bi * p0r;
+    }
+}
+
 template <int N, int Q>
 __device__ __forceinline__ void apply_su2(double (&re)[Cfg<N>::R], double (&im)[Cfg<N>::R],
                                           double ar, double sai, double sbr, double bi) {
     using C = Cfg<N>;
-    if constexpr (Q < C::LB) {
+    if constexpr (kSwapQubit<N, Q>) {
+        swap_frame<N, Q>(re, im);
+        su2_in_lane<N, 1>(re, im, ar, sai, sbr, bi);      // variant 0 of the gate table: unsigned
+        swap_frame<N, Q>(re, im);
+    } else if constexpr (Q < C::LB) {
 #pragma unroll
         for (int r = 0; r < C::R; ++r) {
             const double pr = re[r], pi = im[r];
@@ -507,6 +553,34 @@ __device__ __forceinline__ void pauli_inner(const double (&pr)[Cfg<N>::R], const
         X = x; Y = y; Z = z;
     }
 }
+// X, Y, Z terms of gate (sub, Q) and the gate's inverse on psi and lambda (backward sweep); u = the lane's variant of the gate.
+// Swap-form qubits: everything in the swapped frame, where the pair is in-lane.
+template <int N, int Q>
+__device__ __forceinline__ void su2_inverse_with_inner(double (&pr)[Cfg<N>::R], double (&pi)[Cfg<N>::R],
+                                                       double (&lr)[Cfg<N>::R], double (&li)[Cfg<N>::R],
+                                                       const double4& u, int lane, double& X, double& Y, double& Z) {
+    if constexpr (kSwapQubit<N, Q>) {
+        swap_frame<N, Q>(pr, pi);
+        swap_frame<N, Q>(lr, li);
+        double x = 0.0, y = 0.0, z = 0.0;
+#pragma unroll
+        for (int r0 = 0; r0 < Cfg<N>::R; r0 += 2) {
+            const int r1 = r0 + 1;
+            x += (lr[r0] * pi[r1] - li[r0] * pr[r1]) + (lr[r1] * pi[r0] - li[r1] * pr[r0]);
+            y += -(lr[r0] * pr[r1] + li[r0] * pi[r1]) + (lr[r1] * pr[r0] + li[r1] * pi[r0]);
+            z += (lr[r0] * pi[r0] - li[r0] * pr[r0]) - (lr[r1] * pi[r1] - li[r1] * pr[r1]);
+        }
+        X = x; Y = y; Z = z;
+        su2_in_lane<N, 1>(pr, pi, u.x, -u.y, -u.z, -u.w);
+        su2_in_lane<N, 1>(lr, li, u.x, -u.y, -u.z, -u.w);
+        swap_frame<N, Q>(pr, pi);
+        swap_frame<N, Q>(lr, li);
+    } else {
+        pauli_inner<N, Q>(pr, pi, lr, li, lane, X, Y, Z);
+        apply_su2<N, Q>(pr, pi, u.x, -u.y, -u.z, -u.w);
+        apply_su2<N, Q>(lr, li, u.x, -u.y, -u.z, -u.w);
+    }
+}
 template <int N, int Q>
 __device__ __forceinline__ double pauli_x_inner(const double (&pr)[Cfg<N>::R], const double (&pi)[Cfg<N>::R],
                                                 const double (&lr)[Cfg<N>::R], const double (&li)[Cfg<N>::R]) {
@@ -547,7 +621,7 @@ __device__ __forceinline__ void basis_change(double (&re)[Cfg<N>::R], double (&i
         static_for<0, N>([&](auto q) {
             constexpr int Q = decltype(q)::value;
             double sbr = DAGGER ? -kR : kR;
-            if constexpr (Q < C::LB) sbr = ((lane >> Q) & 1) ? -sbr : sbr;
+            if constexpr (Q < C::LB && !kSwapQubit<N, Q>) sbr = ((lane >> Q) & 1) ? -sbr : sbr;   // (swap form: unsigned)
             apply_su2<N, Q>(re, im, kR, 0.0, sbr, 0.0);
         });
     } else if (pauli == 2) {
@@ -621,7 +695,7 @@ struct GateStream {
         lane16 = loader ? (unsigned)lane * 16u : 0u;
         static_for<0, N>([&](auto q) {
             constexpr int Q = decltype(q)::value;
-            voff[Q] = (Q < C::LB) ? (((unsigned)lane >> Q) & 1u) * 32u : 0u;
+            voff[Q] = (Q < C::LB && !kSwapQubit<N, Q>) ? (((unsigned)lane >> Q) & 1u) * 32u : 0u;   // swap-form qubits: variant 0
         });
     }
     __device__ __forceinline__ char* buf(int s) const { return ring + ((s & 1) ? SUBBYTES : 0); }
@@ -1063,9 +1137,7 @@ __global__ __launch_bounds__(kWaves * 64, MINW) void bwd_kernel(Runs runs, long 
                 static_rfor<0, N>([&](auto q) {
                     constexpr int Q = decltype(q)::value;
                     const double4 u = gs.template cur<false, Q>();
-                    pauli_inner<N, Q>(pr, pi, lr, li, lane, acc3[3 * Q], acc3[3 * Q + 1], acc3[3 * Q + 2]);
-                    apply_su2<N, Q>(pr, pi, u.x, -u.y, -u.z, -u.w);
-                    apply_su2<N, Q>(lr, li, u.x, -u.y, -u.z, -u.w);
+                    su2_inverse_with_inner<N, Q>(pr, pi, lr, li, u, lane, acc3[3 * Q], acc3[3 * Q + 1], acc3[3 * Q + 2]);
                     gs.template done<false, Q>();
                 });
                 gs.template advance<false>();
