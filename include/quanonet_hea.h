@@ -86,7 +86,8 @@ int qhea_device_count(void);
 #define QHEA_BWD_ZPACKED 5     /* one wave per sample group in the ZYZ form (what AUTO runs once the batch fills the  */
                                /* SIMDs, for circuits whose blocks are one full RX chunk + 1 or 2 sub-layers)         */
 #define QHEA_BWD_ZTRI2  6      /* ZTRI with two sample groups per workgroup whose gradient sums are added in LDS: half */
-                               /* the partial rows (12 MB less HBM traffic per cfg-2 step) for ~3 us more kernel time  */
+                               /* the partial rows.  AUTO does that only where it costs nothing (batches that fill     */
+                               /* every CU's two slots); ZTRI2 forces it from one group per CU on, ZTRI never does it   */
 int qhea_set_backward_variant(int variant);
 
 /*

@@ -475,12 +475,17 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     }
     L.zL = zok ? zyz_layer_count(sh.runs, n) : 0;
     L.zsplit = zok && zsplit_eligible(n, sh.E, sh.runs);
-    // QHEA_BWD_ZTRI2: two pipelines per workgroup once two workgroups would share a CU anyway, if both fit its LDS.
-    // Measured at cfg 2, B = 1024: HBM traffic per step 30.5 -> 18.9 MB, circuit kernel 99.3 -> 102.8 us (shallower
-    // hand-off rings to fit, one 8-wave workgroup per CU), reduce kernel unchanged (it is latency-bound) -- so AUTO
-    // keeps one pipeline per workgroup.
+    // Two pipelines per workgroup (their sigma waves add the two groups' sums in LDS: half the partial rows, -6 MB of HBM
+    // traffic per cfg-2 step, bwd_ztri_kernel<N, 2>).  Measured at cfg 2 (us per step, one / two pipelines): B = 1024
+    // 103.1 / 103.3, 960 103.3 / 103.7, 896 102.6 / 103.2, 768 101.8 / 102.6, 640 99.9 / 101.5, 1280 156 / 189 -- a wash
+    // where every CU holds two sample groups anyway, a loss elsewhere (10-wave workgroups, one per CU).  AUTO therefore takes
+    // two pipelines only when the groups fill more than 7/8 of the CUs' two slots; QHEA_BWD_ZTRI2 forces them wherever two
+    // workgroups would share a CU, QHEA_BWD_ZTRI never.
     L.zpipes = 1;
-    if (L.ztri && var == QHEA_BWD_ZTRI2 && L.nwaves > (long)simd_count() / 4) {
+    const long cus = (long)simd_count() / 4;
+    const bool two_wanted = var == QHEA_BWD_ZTRI2 ? L.nwaves > cus
+                                                  : (var == QHEA_BWD_AUTO && 8 * L.nwaves > 14 * cus && L.nwaves <= 2 * cus);
+    if (L.ztri && two_wanted) {
         const size_t cs_bytes = (size_t)(64 >> n) * zyz_cs_row(n, sh.E) * (L.zsplit ? 32 : 16);
         const size_t lds = 2 * ztri_fixed_lds(kZRingDepth<2>) + 2 * cs_bytes +
                            (size_t)sh.blk * padded_3n(n) * sizeof(double);

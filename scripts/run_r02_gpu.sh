@@ -10,10 +10,10 @@ python3 scripts/summarize_profiles.py $TAG > gpurun_out/summary_$TAG.txt 2>&1; t
 # 2 ranks on the one GPU (gloo moves the 19 KB through the host): the data-parallel step sequence end to end
 timeout -k 10 300 python3 bench.py --gpus 2 --same-device --backend gloo --steps 100 --no-cpu-baseline > gpurun_out/dp2_same_device_$TAG.json 2> gpurun_out/dp2_same_device_$TAG.err; echo "dp2 rc=$?"; cut -c1-250 gpurun_out/dp2_same_device_$TAG.json
 timeout -k 10 120 python3 -m torch.distributed.run --standalone --nproc-per-node 1 scripts/allreduce_cost.py > gpurun_out/allreduce_cost_$TAG.json 2> gpurun_out/allreduce_cost_$TAG.err; echo "allreduce rc=$?"; cat gpurun_out/allreduce_cost_$TAG.json
-# batch sweep of every n <= 5 kernel variant at cfg 2's circuit, and the two-pipeline variant's bench line + HBM counters
+# batch sweep of every n <= 5 kernel variant at cfg 2 circuit, and bench line + HBM counters with ONE pipeline per workgroup (AUTO takes two at this batch)
 timeout -k 10 300 python3 scripts/ablate/bsweep_all.py > gpurun_out/bsweep_$TAG.txt 2>&1; echo "bsweep rc=$?"; cat gpurun_out/bsweep_$TAG.txt
-timeout -k 10 120 python3 bench.py --no-cpu-baseline --backward-variant ztri2 > gpurun_out/bench_ztri2_$TAG.json 2>/dev/null; echo "ztri2 rc=$?"; cut -c1-200 gpurun_out/bench_ztri2_$TAG.json
+timeout -k 10 120 python3 bench.py --no-cpu-baseline --backward-variant ztri > gpurun_out/bench_ztri1_$TAG.json 2>/dev/null; echo "ztri (one pipeline per workgroup) rc=$?"; cut -c1-200 gpurun_out/bench_ztri1_$TAG.json
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for grp in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/prof_${TAG}_ztri2/pmc_$grp -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --backward-variant ztri2 > gpurun_out/prof_${TAG}_ztri2_$grp.log 2>&1 || echo "pass $grp failed"
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/prof_${TAG}_ztri1/pmc_$grp -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --backward-variant ztri > gpurun_out/prof_${TAG}_ztri1_$grp.log 2>&1 || echo "pass $grp failed"
 done

@@ -19,7 +19,11 @@ if glob.glob(f'{src}/trace/*/*_kernel_stats.csv'):                  # (a counter
         for r in rows:
             w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage']])
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(f'{src}/pmc_*/*/*counter_collection.csv'):
+pmc_files = []
+for d in glob.glob(f'{src}/pmc_*'):                                 # gpurun merges runs into the same directory: newest pass only
+    if os.path.isdir(d) and glob.glob(f'{d}/*/*counter_collection.csv'):
+        pmc_files.append(newest(f'{d}/*/*counter_collection.csv'))
+for f in pmc_files:
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
         if 'qhea' not in k:
