@@ -1279,6 +1279,11 @@ __device__ __forceinline__ bool pair_wait_ge(int* counter, int target, int* abor
         if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
         __builtin_amdgcn_s_sleep(2);
     }
+#ifdef QHEA_DEBUG_ABORT     // debugging build: say which wait overran (LDS address of the counter, target, last value seen)
+    if ((threadIdx.x & 63) == 0)
+        printf("overrun: block %d wave %d waited for counter@%u >= %d, saw %d\n", (int)blockIdx.x, (int)(threadIdx.x >> 6),
+               (unsigned)(unsigned long long)(__attribute__((address_space(3))) int*)counter, target, seen);
+#endif
     __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return false;
 }

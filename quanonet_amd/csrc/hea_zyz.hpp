@@ -1107,6 +1107,10 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
                 return v;
             };
             int mine = __builtin_amdgcn_readfirstlane(draw());
+            // A wave that draws late may get a first step beyond the ring depth, and the chains would wait forever for a cursor
+            // that still says 0 (seen with six waves on an 8-entry ring: caught by the overrun report): it reads nothing below
+            // `mine`, so say so at once.
+            __hip_atomic_store(&sync.cursor[me], mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             int after_v = draw();
             while (mine < nsteps) {
                 const int t = mine;

@@ -103,3 +103,35 @@ def test_status_is_clean_after_healthy_runs():
         _lib.check_status(dev)
     with pytest.raises(ValueError):
         _lib.set_backward_variant('fastest')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant,batch', [('auto', 1024), ('ztri', 1024), ('ztri2', 640), ('ztri2', 1024), ('auto', 512)])
+def test_many_training_steps_never_overrun(variant, batch):
+    """60 training steps of the headline model (cfg 2) with the status word checked after every step, at the batches
+    where the pipeline kernel runs one / two workgroups per CU and one / two pipelines per workgroup.  A hand-off
+    protocol error that only shows under particular timings (one did in round 2: a sigma wave drawing its first step
+    beyond the ring depth) surfaces here as QHEA_EPIPELINE instead of passing a single-call parity test."""
+    import numpy as np
+    import torch
+    from quanonet_amd import _lib
+    from quanonet_amd.models import QuanONetPT
+    from quanonet_amd.solver import DataParallelTrainer
+    dev = torch.device('cuda:0')
+    _lib.set_backward_variant(variant)
+    try:
+        torch.manual_seed(0)
+        rng = np.random.default_rng(3)
+        model = QuanONetPT(5, 100, 2, (40, 2, 20, 2), scale_coeff=0.1, if_trainable_freq=True).to(dev)
+        tr = DataParallelTrainer(model, lr=1e-4, world_size=1, dist=None)
+        br = torch.tensor(rng.normal(size=(2 * batch, 100)), device=dev)
+        tk = torch.tensor(rng.uniform(size=(2 * batch, 2)), device=dev)
+        y = torch.tensor(rng.normal(size=2 * batch), device=dev)
+        for i in range(60):
+            s = (i % 2) * batch
+            flat = tr.train_step(br[s:s + batch], tk[s:s + batch], y[s:s + batch], global_batch=batch)
+            torch.cuda.synchronize()
+            _lib.check_status(dev)                      # raises QheaError(-6) on an overrun
+            assert torch.isfinite(flat).all(), i
+    finally:
+        _lib.set_backward_variant('auto')
