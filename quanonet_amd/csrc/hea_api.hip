@@ -471,7 +471,7 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     L.zpacked = zp_ok && ((var == QHEA_BWD_AUTO && !L.pair) || var == QHEA_BWD_ZPACKED);
     if (L.zpacked) {
         L.pair = false; L.ztri = false;
-        L.nwaves = ((B + spw - 1) / spw + kZPWaves - 1) / kZPWaves * kZPWaves;      // one partial row per wave, padding waves write zeros
+        L.nwaves = ((B + spw - 1) / spw + kZPWaves - 1) / kZPWaves;                 // one partial row per WORKGROUP (its four waves' sums added in LDS)
     }
     L.zL = zok ? zyz_layer_count(sh.runs, n) : 0;
     L.zsplit = zok && zsplit_eligible(n, sh.E, sh.runs);
@@ -571,7 +571,7 @@ int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char
     const size_t dyn = (size_t)(64 >> n) * zyz_cs_row(n, sh.E) * sizeof(double2);
     if (L.zpacked) {
         switch (n) {
-#define QHEA_CASE(NN) case NN: launch_bwd_zpacked_##NN(dim3((unsigned)(L.nwaves / kZPWaves)), dyn * kZPWaves, st, za); break;
+#define QHEA_CASE(NN) case NN: launch_bwd_zpacked_##NN(dim3((unsigned)L.nwaves), zp_cs_bytes(n, sh.E, kZPWaves * (64 >> n)), st, za); break;
             QHEA_FOR_EACH_ZN(QHEA_CASE)
 #undef QHEA_CASE
             default: return QHEA_EUNSUPPORTED;

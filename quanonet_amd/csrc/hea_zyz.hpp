@@ -69,8 +69,9 @@ __device__ __forceinline__ double enc_angle(const AngleSrc& a, int E, long b, in
 }
 // rows [s0, s0 + ns) x E of the group's table, spread over `nthreads` threads (tid of them); samples past the batch
 // repeat the last one (their lanes carry lambda = 0)
-__device__ __forceinline__ void fill_cs(double2* cs, const AngleSrc& src, int n, int E, long b0, long B, int ns, int tid, int nthreads) {
-    const int row = (int)zyz_cs_row(n, E);
+__device__ __forceinline__ void fill_cs(double2* cs, const AngleSrc& src, int n, int E, long b0, long B, int ns, int tid, int nthreads,
+                                        int row_stride = 0 /* 0: zyz_cs_row(n, E) */) {
+    const int row = row_stride ? row_stride : (int)zyz_cs_row(n, E);
     for (int s = 0; s < ns; ++s) {
         const long b = (b0 + s < B) ? b0 + s : B - 1;
         for (int e = tid; e < E; e += nthreads) {
@@ -1233,6 +1234,11 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
 // Only wire 4's partner fetch for the inner products (4 ds_swizzle per layer) and the ring gathers use the LDS pipe.
 // ---------------------------------------------------------------------------------------
 constexpr int kZPWaves = 4;
+// row stride of the one-wave kernel's (cos, sin) tables: neighbouring rows SHARE their n entries of padding (padding is only
+// ever read ahead, never used), n more entries follow the last row -- 640 bytes less per workgroup, which is what keeps three
+// workgroups (54 KB each with the sums' staging area, in 1280-byte LDS granules) on a CU
+__host__ __device__ inline long zp_cs_row(int n, long E) { return E + n; }
+__host__ __device__ inline size_t zp_cs_bytes(int n, long E, int rows) { return ((size_t)rows * zp_cs_row(n, E) + n) * sizeof(double2); }
 
 // psi <- RY_Q^-1 psi, lambda <- RY_Q^-1 lambda, and this lane's terms of X,Y,Z = Im<lambda|sigma_Q|psi> taken before
 template <int Q>
@@ -1278,12 +1284,12 @@ __device__ __forceinline__ void enc_inv_with_inner(double (&pr)[1], double (&pi)
 
 template <int N, int LD>
 __device__ __forceinline__ void zpacked_body(const ZBwdArgs& a, int wib, int lane, int klow, bool valid, long b, long wave,
-                                             const double2* cs, char* wg_ring) {
+                                             const double2* cs, char* wg_ring, double* comb /* [2][kZPWaves][2 * KW] */) {
     using C = Cfg<N>;
     const int E = a.E;
     const int ring_fwd = ring_source<N>(lane, false);
     const int ring_rev = ring_source<N>(lane, true);
-    const double2* csrow = cs + (wib * C::SPW + (lane >> C::LB)) * (int)zyz_cs_row(N, E) + N;
+    const double2* csrow = cs + (wib * C::SPW + (lane >> C::LB)) * (int)zp_cs_row(N, E) + N;
     BlockStream<N, LD, true> bs;
     bs.init(a.rec, a.L + 1, wg_ring, lane, klow);
     bs.loader = wib == 0;
@@ -1321,11 +1327,27 @@ __device__ __forceinline__ void zpacked_body(const ZBwdArgs& a, int wib, int lan
     int sub = a.blk;
     const double2* cs_b = csrow + (long)(nb - 1) * N;             // chunk of the block at hand (every block has enc = n)
     bs.load_cs(cs_b, 0);
-    double* __restrict__ part_w = a.partial + wave * (long)a.blk * C::KW;
+    // The workgroup's four waves walk the blocks in step (one barrier per block, BlockStream<SHARED>), so their gradient sums
+    // are combined before they leave the chip: every wave parks a block's sums in LDS, and after the next block's barrier one
+    // wave adds the four in a fixed order and writes ONE row per workgroup -- a quarter of the partial rows (B = 16384 at cfg 2:
+    // 63 MB instead of 252 MB written and read back per call).
+    double* __restrict__ row_w = a.partial + (long)blockIdx.x * a.blk * C::KW;
+    constexpr int kSlotVals = 2 * C::KW;                          // room for LD <= 2 sub-layers of KW values
+    auto combine = [&](int blk_done) {                            // the sums of block `blk_done` (parked before the last barrier)
+        if (wib == (blk_done & (kZPWaves - 1)) && lane < LD * C::KW) {
+            const double* c = comb + (blk_done & 1) * (kZPWaves * kSlotVals) + lane;
+            double t = c[0];
+#pragma unroll
+            for (int w = 1; w < kZPWaves; ++w) t += c[w * kSlotVals];
+            row_w[((long)blk_done * LD + lane / C::KW) * C::KW + lane % C::KW] = t;
+        }
+    };
     // one block, sitting in ring slot `sl` (walk unrolled over the ring slots like the other block walks)
     auto block = [&](auto sl, int bl, int kb) {
         bs.landed();
+        if (bl + 1 < nb) combine(bl + 1);
         const char* nx = bs.template slot_rel<-1>(sl);
+        double* park = comb + (bl & 1) * (kZPWaves * kSlotVals) + wib * kSlotVals;
 #pragma unroll
         for (int s = LD - 1; s >= 0; --s) {
             if (s != LD - 1) {
@@ -1346,7 +1368,7 @@ __device__ __forceinline__ void zpacked_body(const ZBwdArgs& a, int wib, int lan
                 bs.ry[s][Q] = bs.rd(nx, (1 + s) * kRecBytes + bs.a_ry[Q]);
             });
             const int vi = butterfly_sum<C::KW>(acc3, lane);
-            if (butterfly_owner<C::KW>(lane)) part_w[(long)sub * C::KW + vi] = acc3[0];
+            if (butterfly_owner<C::KW>(lane)) park[s * C::KW + vi] = acc3[0];
         }
         apply_phase<true>(pr[0], pi[0], bs.dg[1]);
         apply_phase<true>(lr[0], li[0], bs.dg[1]);
@@ -1378,6 +1400,8 @@ __device__ __forceinline__ void zpacked_body(const ZBwdArgs& a, int wib, int lan
         block(CtSlot<0>{}, bl - 3, 3);
         cs_b -= kBSlots * N;
     }
+    __syncthreads();
+    combine(0);
 }
 
 template <int N>
@@ -1386,6 +1410,7 @@ __global__ __launch_bounds__(kZPWaves * 64) void bwd_zpacked_kernel(ZBwdArgs a) 
     static_assert(C::R == 1, "all-lane layout");
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // kZPWaves x SPW x (E + 2N) (cos, sin)
     __shared__ __attribute__((aligned(16))) char wg_ring[kBlockRingBytes];          // ONE record ring per workgroup
+    __shared__ double comb[2 * kZPWaves * 2 * C::KW];                               // the waves' sums of two blocks (zpacked_body)
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long wave = (long)blockIdx.x * kZPWaves + wib;
@@ -1394,10 +1419,11 @@ __global__ __launch_bounds__(kZPWaves * 64) void bwd_zpacked_kernel(ZBwdArgs a) 
     const long b = valid ? b_raw : a.B - 1;
     const int klow = lane & (C::LANES - 1);
     double2* cs = reinterpret_cast<double2*>(dyn_lds);
-    fill_cs(cs, a.src, N, a.E, (long)blockIdx.x * kZPWaves * C::SPW, a.B, kZPWaves * C::SPW, (int)threadIdx.x, kZPWaves * 64);
+    fill_cs(cs, a.src, N, a.E, (long)blockIdx.x * kZPWaves * C::SPW, a.B, kZPWaves * C::SPW, (int)threadIdx.x, kZPWaves * 64,
+            (int)zp_cs_row(N, a.E));
     __syncthreads();
-    if (a.fast_ld == 2) zpacked_body<N, 2>(a, wib, lane, klow, valid, b, wave, cs, wg_ring);
-    else zpacked_body<N, 1>(a, wib, lane, klow, valid, b, wave, cs, wg_ring);
+    if (a.fast_ld == 2) zpacked_body<N, 2>(a, wib, lane, klow, valid, b, wave, cs, wg_ring, comb);
+    else zpacked_body<N, 1>(a, wib, lane, klow, valid, b, wave, cs, wg_ring, comb);
 }
 
 // Forward-only counterpart for batches that fill the SIMDs: four sweeping waves per workgroup on ONE shared record ring
