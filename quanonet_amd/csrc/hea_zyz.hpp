@@ -82,6 +82,15 @@ __device__ __forceinline__ void fill_cs(double2* cs, const AngleSrc& src, int n,
     }
 }
 
+// The Y and Z inner products carry the lane's sign (-1)^(bit Q of the lane).  A multiplication by +-1.0 costs an fp64
+// operation plus the instructions that materialise the +-1.0 from the lane index (the compiler recomputes them inside the
+// loops once registers are tight); flipping the sign bit is one 32-bit XOR with a mask that is two integer instructions away.
+template <int Q>
+__device__ __forceinline__ unsigned lane_sign_mask(int lane) { return ((unsigned)lane << (31 - Q)) & 0x80000000u; }
+__device__ __forceinline__ double flip_sign(double v, unsigned mask) {          // -v where the lane's bit is set, v elsewhere
+    return __hiloint2double(__double2hiint(v) ^ (int)mask, __double2loint(v));
+}
+
 // (re, im) <- e^{+-i Phi} (re, im), d = (cos Phi, sin Phi)
 template <bool DAGGER>
 __device__ __forceinline__ void apply_phase(double& re, double& im, const double2& d) {
@@ -1077,10 +1086,10 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
             for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
             static_for<0, N>([&](auto q) {
                 constexpr int Q = decltype(q)::value;
-                const double sg = ((lane >> Q) & 1) ? -1.0 : 1.0;
+                const unsigned m = lane_sign_mask<Q>(lane);
                 acc3[3 * Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
-                acc3[3 * Q + 1] = -sg * (lm.x * qv[Q].x + lm.y * qv[Q].y);
-                acc3[3 * Q + 2] = sg * (lm.x * p.y - lm.y * p.x);
+                acc3[3 * Q + 1] = flip_sign(-(lm.x * qv[Q].x) - lm.y * qv[Q].y, m);     // -sg (...), sg = (-1)^bit
+                acc3[3 * Q + 2] = flip_sign(lm.x * p.y - lm.y * p.x, m);                 //  sg (...)
             });
         };
         auto store_sums = [&](double (&acc3)[C::KW], int sub) {
@@ -1192,8 +1201,7 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
                         for_gates_below<N>(m, [&](auto q) {
                             constexpr int Q = decltype(q)::value;
                             if constexpr (Q == 4) {           // this wire's encoding gate runs as RY (apply_enc): Y inner product
-                                const double sg = ((lane >> Q) & 1) ? -1.0 : 1.0;
-                                gx[Q] = -sg * (lm.x * qv[Q].x + lm.y * qv[Q].y);
+                                gx[Q] = flip_sign(-(lm.x * qv[Q].x) - lm.y * qv[Q].y, lane_sign_mask<Q>(lane));
                             } else {
                                 gx[Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
                             }
@@ -1244,19 +1252,19 @@ __host__ __device__ inline size_t zp_cs_bytes(int n, long E, int rows) { return 
 template <int Q>
 __device__ __forceinline__ void ry_inv_with_inner(double& pr, double& pi, double& lr, double& li, const double2& u, int lane,
                                                   double& X, double& Y, double& Z) {
-    const double sg = ((lane >> Q) & 1) ? -1.0 : 1.0;
+    const unsigned m = lane_sign_mask<Q>(lane);
     if constexpr (Q == 4) {
         const double qr = xchg<16>(pr), qi = xchg<16>(pi);
         X = lr * qi - li * qr;
-        Y = -sg * (lr * qr + li * qi);
-        Z = sg * (lr * pi - li * pr);
+        Y = flip_sign(-(lr * qr) - li * qi, m);
+        Z = flip_sign(lr * pi - li * pr, m);
         apply_ry<4, true>(pr, pi, u);
         apply_ry<4, true>(lr, li, u);
     } else {
         const double qr = xchg<(1 << Q)>(pr), qi = xchg<(1 << Q)>(pi);
         X = lr * qi - li * qr;
-        Y = -sg * (lr * qr + li * qi);
-        Z = sg * (lr * pi - li * pr);
+        Y = flip_sign(-(lr * qr) - li * qi, m);
+        Z = flip_sign(lr * pi - li * pr, m);
         pr = u.x * pr - u.y * qr;                 // RY^-1: sv -> -sv
         pi = u.x * pi - u.y * qi;
         apply_ry<Q, true>(lr, li, u);
@@ -1267,9 +1275,8 @@ template <int N, int Q>
 __device__ __forceinline__ void enc_inv_with_inner(double (&pr)[1], double (&pi)[1], double (&lr)[1], double (&li)[1],
                                                    const double2& cs, int lane, double& G) {
     if constexpr (Q == 4) {
-        const double sg = ((lane >> Q) & 1) ? -1.0 : 1.0;
         const double qr = xchg<16>(pr[0]), qi = xchg<16>(pi[0]);
-        G = -sg * (lr[0] * qr + li[0] * qi);
+        G = flip_sign(-(lr[0] * qr) - li[0] * qi, lane_sign_mask<Q>(lane));
         apply_ry<4, true>(pr[0], pi[0], cs);
         apply_ry<4, true>(lr[0], li[0], cs);
     } else {
