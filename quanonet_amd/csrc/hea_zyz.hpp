@@ -1122,10 +1122,12 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
             // `mine`, so say so at once.
             __hip_atomic_store(&sync.cursor[me], mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             int after_v = draw();
-            while (mine < nsteps) {
+            // one step; CHUNK: it also carries the block's RX-chunk gradients.  Two instantiations rather than a run-time test
+            // inside: with the axes loaded conditionally the compiler copies all fifteen at the join of the two paths.
+            auto sigma_step = [&](auto chunk_c) {
+                constexpr bool CHUNK = decltype(chunk_c)::value;
                 const int t = mine;
                 const int j = LDr == 2 ? (t >> 1) : t;         // block, in walking order
-                const bool chunk = LDr == 2 ? (t & 1) : true;  // the block's first sub-layer (its last step)
                 const int sub = a.blk - 1 - t, bl = a.nblocks - 1 - j;
                 pair_wait_ge(&sync.psi_prod, t + 1, &sync.abort, seen_p);
                 pair_wait_ge(&sync.lam_prod, t + 1, &sync.abort, seen_l);
@@ -1134,8 +1136,8 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
                 double2 qv[N];
                 static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
                 const double2 lm = lam_ring[t & (RING - 1)][lane];
-                double em[3 * N];
-                if (chunk) {
+                double em[CHUNK ? 3 * N : 1];
+                if constexpr (CHUNK) {
                     const double* __restrict__ e = axis_ring + (bl & (kAxisRing - 1)) * (3 * N);
 #pragma unroll
                     for (int i = 0; i < 3 * N; ++i) em[i] = e[i];
@@ -1145,20 +1147,24 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
                 after_v = draw();
                 double acc3[C::KW];
                 products(acc3, p, qv, lm);
-                double gx[C::KX];
-                if (chunk) {
+                if constexpr (CHUNK) {
+                    double gx[C::KX];
 #pragma unroll
                     for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
                     static_for<0, N>([&](auto q) {
                         constexpr int Q = decltype(q)::value;
                         gx[Q] = em[3 * Q] * acc3[3 * Q] + em[3 * Q + 1] * acc3[3 * Q + 1] + em[3 * Q + 2] * acc3[3 * Q + 2];
                     });
-                }
-                store_sums(acc3, sub);
-                if (chunk) {
+                    store_sums(acc3, sub);
                     if constexpr (N == 5) store_grad_x5(gx, lane, wave, a.B, E, a.grad_x, bl * N, N);
                     else store_grad_x<N>(gx, lane, wave, a.B, E, a.grad_x, bl * N, N);
+                } else {
+                    store_sums(acc3, sub);
                 }
+            };
+            while (mine < nsteps) {
+                if (LDr == 1 || (mine & 1)) sigma_step(std::true_type{});     // the block's first sub-layer is its last step
+                else sigma_step(std::false_type{});
             }
         } else {
             // other shapes: the chains publish at every layer, sigma wave w takes the steps t = w (mod kZSigma)
