@@ -534,9 +534,9 @@ __device__ __forceinline__ void pauli_inner(const double (&pr)[Cfg<N>::R], const
 #pragma unroll
         for (int r = 0; r < C::R; ++r) {
             const double qr = xchg<(1 << Q)>(pr[r]), qi = xchg<(1 << Q)>(pi[r]);
-            x += lr[r] * qi - li[r] * qr;
-            y += lr[r] * qr + li[r] * qi;
-            z += lr[r] * pi[r] - li[r] * pr[r];
+            x = fma(-li[r], qr, fma(lr[r], qi, x));          // FMA chains: 2 instead of 3 fp64 instructions each
+            y = fma(li[r], qi, fma(lr[r], qr, y));
+            z = fma(-li[r], pr[r], fma(lr[r], pi[r], z));
         }
         const double s = ((lane >> Q) & 1) ? -1.0 : 1.0;
         X = x; Y = -s * y; Z = s * z;
@@ -546,9 +546,9 @@ __device__ __forceinline__ void pauli_inner(const double (&pr)[Cfg<N>::R], const
         for (int r0 = 0; r0 < C::R; ++r0) {
             if (r0 & J) continue;
             const int r1 = r0 | J;
-            x += (lr[r0] * pi[r1] - li[r0] * pr[r1]) + (lr[r1] * pi[r0] - li[r1] * pr[r0]);
-            y += -(lr[r0] * pr[r1] + li[r0] * pi[r1]) + (lr[r1] * pr[r0] + li[r1] * pi[r0]);
-            z += (lr[r0] * pi[r0] - li[r0] * pr[r0]) - (lr[r1] * pi[r1] - li[r1] * pr[r1]);
+            x = fma(-li[r1], pr[r0], fma(lr[r1], pi[r0], fma(-li[r0], pr[r1], fma(lr[r0], pi[r1], x))));
+            y = fma(li[r1], pi[r0], fma(lr[r1], pr[r0], fma(-li[r0], pi[r1], fma(-lr[r0], pr[r1], y))));
+            z = fma(li[r1], pr[r1], fma(-lr[r1], pi[r1], fma(-li[r0], pr[r0], fma(lr[r0], pi[r0], z))));
         }
         X = x; Y = y; Z = z;
     }
@@ -566,9 +566,9 @@ __device__ __forceinline__ void su2_inverse_with_inner(double (&pr)[Cfg<N>::R], 
 #pragma unroll
         for (int r0 = 0; r0 < Cfg<N>::R; r0 += 2) {
             const int r1 = r0 + 1;
-            x += (lr[r0] * pi[r1] - li[r0] * pr[r1]) + (lr[r1] * pi[r0] - li[r1] * pr[r0]);
-            y += -(lr[r0] * pr[r1] + li[r0] * pi[r1]) + (lr[r1] * pr[r0] + li[r1] * pi[r0]);
-            z += (lr[r0] * pi[r0] - li[r0] * pr[r0]) - (lr[r1] * pi[r1] - li[r1] * pr[r1]);
+            x = fma(-li[r1], pr[r0], fma(lr[r1], pi[r0], fma(-li[r0], pr[r1], fma(lr[r0], pi[r1], x))));
+            y = fma(li[r1], pi[r0], fma(lr[r1], pr[r0], fma(-li[r0], pi[r1], fma(-lr[r0], pr[r1], y))));
+            z = fma(li[r1], pr[r1], fma(-lr[r1], pi[r1], fma(-li[r0], pr[r0], fma(lr[r0], pi[r0], z))));
         }
         X = x; Y = y; Z = z;
         su2_in_lane<N, 1>(pr, pi, u.x, -u.y, -u.z, -u.w);
@@ -590,7 +590,7 @@ __device__ __forceinline__ double pauli_x_inner(const double (&pr)[Cfg<N>::R], c
 #pragma unroll
         for (int r = 0; r < C::R; ++r) {
             const double qr = xchg<(1 << Q)>(pr[r]), qi = xchg<(1 << Q)>(pi[r]);
-            x += lr[r] * qi - li[r] * qr;
+            x = fma(-li[r], qr, fma(lr[r], qi, x));
         }
     } else {
         constexpr int J = 1 << (Q - C::LB);
@@ -598,7 +598,7 @@ __device__ __forceinline__ double pauli_x_inner(const double (&pr)[Cfg<N>::R], c
         for (int r0 = 0; r0 < C::R; ++r0) {
             if (r0 & J) continue;
             const int r1 = r0 | J;
-            x += (lr[r0] * pi[r1] - li[r0] * pr[r1]) + (lr[r1] * pi[r0] - li[r1] * pr[r0]);
+            x = fma(-li[r1], pr[r0], fma(lr[r1], pi[r0], fma(-li[r0], pr[r1], fma(lr[r0], pi[r1], x))));
         }
     }
     return x;

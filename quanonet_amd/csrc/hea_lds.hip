@@ -66,6 +66,26 @@ struct Pass {
     static constexpr int A = (LG * P + LG <= N) ? LG * P : N - LG;     // lowest of the LG index bits held per thread
 };
 
+// Which passes need a workgroup barrier between them.  thread_part maps the lane bits of a thread (t bits 0..5) and
+// the pass's LG local bits onto index bits [0, 6 + LG) whenever A <= 6, and the wave number onto the bits above: the
+// passes with A <= 6 (LG = 3: A = 0, 3, 6; LG = 4: A = 0, 4) all work on the SAME 2^(6+LG) amplitudes per wave.  Between
+// two of them only the wave's own LDS accesses have to stay in order -- which the LDS pipe does for one wave's
+// instructions -- so the waves of a workgroup drift apart there and one wave's LDS round trip overlaps another's
+// arithmetic (with a barrier after every pass all waves load, compute and store in step: no overlap with one
+// workgroup per CU).  Only the last pass (index bits above 6 + LG) exchanges amplitudes between waves.
+template <int N, int LG, int PA, int PB>
+constexpr bool wave_local_passes() { return Pass<N, PA, LG>::A <= 6 && Pass<N, PB, LG>::A <= 6; }
+template <bool WAVE_LOCAL>
+__device__ __forceinline__ void pass_sync() {
+    if constexpr (WAVE_LOCAL) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // compiler ordering only: stores before ...
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // ... the next pass's loads
+    } else {
+        __syncthreads();
+    }
+}
+
 // LDS index swizzle (an involution, linear over GF(2)): whatever the pass, the 16-byte accesses of 16 neighbouring
 // lanes fall into 16 different bank quads.  LG = 4: bits 0..3 ^= bits 4..7.  LG = 3 (passes at bits 0, 3, 6, 9 or a
 // ragged last one): bits 0..2 ^= bits 4..6 and bit 3 ^= bit 6.
@@ -105,15 +125,16 @@ __device__ __forceinline__ void set_gates(double4* gtab, F f) {
     if (threadIdx.x < N) gtab[threadIdx.x] = f((int)threadIdx.x);
     __syncthreads();
 }
-// Im<l|sigma|p> contributions of one pair (p0,p1),(l0,l1)
+// Im<l|sigma|p> contributions of one pair (p0,p1),(l0,l1), accumulated as FMA chains: 4 fp64 instructions per product
+// (written as sums of differences the compiler may not reassociate: mul, fma, mul, fma, add, add)
+__device__ __forceinline__ void inner_x(const c2& p0, const c2& p1, const c2& l0, const c2& l1, double& X) {
+    X = fma(l0.x, p1.y, X); X = fma(-l0.y, p1.x, X); X = fma(l1.x, p0.y, X); X = fma(-l1.y, p0.x, X);
+}
 __device__ __forceinline__ void inner(const c2& p0, const c2& p1, const c2& l0, const c2& l1, double& X, double& Y,
                                       double& Z) {
-    X += (l0.x * p1.y - l0.y * p1.x) + (l1.x * p0.y - l1.y * p0.x);
-    Y += -(l0.x * p1.x + l0.y * p1.y) + (l1.x * p0.x + l1.y * p0.y);
-    Z += (l0.x * p0.y - l0.y * p0.x) - (l1.x * p1.y - l1.y * p1.x);
-}
-__device__ __forceinline__ void inner_x(const c2& p0, const c2& p1, const c2& l0, const c2& l1, double& X) {
-    X += (l0.x * p1.y - l0.y * p1.x) + (l1.x * p0.y - l1.y * p0.x);
+    inner_x(p0, p1, l0, l1, X);
+    Y = fma(-l0.x, p1.x, Y); Y = fma(-l0.y, p1.y, Y); Y = fma(l1.x, p0.x, Y); Y = fma(l1.y, p0.y, Y);
+    Z = fma(l0.x, p0.y, Z); Z = fma(-l0.y, p0.x, Z); Z = fma(-l1.x, p1.y, Z); Z = fma(l1.y, p1.x, Z);
 }
 
 // the 2^LG amplitudes of this thread for a pass with base bit A: local index j <-> index bits A..A+LG-1.
@@ -175,10 +196,12 @@ __device__ __forceinline__ void fwd_layer(double2* s, const Bases<N, LG>& bs, G 
         if constexpr (RING && P == NP - 1) {
             __syncthreads();                               // every thread holds its amplitudes: safe to permute
             store_group<N, PS::A, true, LG>(s, bs.ring, v);
+            __syncthreads();
         } else {
             store_group<N, PS::A, false, LG>(s, bs.plain[P], v);
+            // the next pass: P + 1, or pass 0 of the following layer
+            pass_sync<wave_local_passes<N, LG, P, (P + 1 < NP ? P + 1 : 0)>()>();
         }
-        __syncthreads();
     });
 }
 
@@ -219,7 +242,8 @@ __device__ __forceinline__ void bwd_layer(double2* psi, double2* lam, const Base
         });
         store_group<N, PS::A, false, LG>(psi, bs.plain[P], v);
         store_group<N, PS::A, false, LG>(lam, bs.plain[P], l);
-        __syncthreads();
+        // the next pass: P - 1, or the last pass of the following (earlier) layer
+        pass_sync<(P > 0) && wave_local_passes<N, LG, P, (P > 0 ? P - 1 : 0)>()>();
     });
 }
 
