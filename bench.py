@@ -221,7 +221,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Advection QuanONet Q=5 Net40-2-20-2 b_in=100 t_in=2, batch {batch} per GPU, "
                                    "fp64, Adam lr=1e-4, trainable frequency",
-                       "global_batch": batch * world, "parallelism": f"dp{world}"},
+                       "global_batch": batch * world, "parallelism": f"dp{world}",
+                       "dp_exchange": (None if world == 1 else
+                                       "peer-mapped buffers, sum + Adam in one kernel (csrc/hea_dp.hip)"
+                                       if trainer.peer is not None else "all_reduce (" + args.backend + ") + Adam launch")},
             "timing": {"windows": len(windows), "steps_per_window": args.steps,
                        "ms_per_step_median": 1e3 * elapsed / args.steps,
                        "ms_per_step_first_window": 1e3 * windows[0] / args.steps,
@@ -233,6 +236,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
+    if trainer.peer is not None:
+        trainer.peer.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -56,6 +56,7 @@ extern "C" {
 #define QHEA_ELAUNCH      -4   /* HIP launch or runtime failure                       */
 #define QHEA_ENODEVICE    -5   /* no usable HIP device                                */
 #define QHEA_EPIPELINE    -6   /* a backward kernel's wave-to-wave hand-off overran (qhea_check_status) */
+#define QHEA_EEXCHANGE    -7   /* a data-parallel exchange did not hear from every rank in time (qhea_dp_status) */
 
 #define QHEA_MIN_QUBITS 2      /* n=1 has no entangler in MindQuantum and an undefined one in TQ */
 #define QHEA_MAX_QUBITS 12
@@ -252,6 +253,43 @@ int qhea_model_train_step(const qhea_model_desc* desc, int64_t batch,
 int qhea_adam_step(int64_t n, double* params /*DEVICE*/, const double* grads /*DEVICE*/,
                    double* exp_avg /*DEVICE*/, double* exp_avg_sq /*DEVICE*/, int64_t step,
                    double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
+
+/*
+ * Data-parallel gradient exchange (the reference has no multi-device step -- this replaces the
+ * `all_reduce` + `optimizer.step()` pair a DistributedDataParallel port of solvers/solver_pt.py:232-237 would run).
+ * Every rank owns ONE exchange buffer of fine-grained device memory that every other rank maps through hipIpc; one
+ * one-workgroup kernel per rank and step writes the rank's flat buffer [gradients | sse | sum y^2] into every rank's
+ * buffer, waits for the other ranks' contributions to its own, sums them in rank order (bitwise identical on every
+ * rank, reproducible) and applies Adam -- no collective-library launch and no separate optimizer launch on the step's
+ * critical path.  Set-up (once): qhea_dp_alloc -> qhea_dp_export -> exchange the 64-byte handles by any means
+ * (torch.distributed.all_gather_object) -> qhea_dp_import each peer's.  The library retains nothing: the caller
+ * owns the buffer and the mapped pointers and passes them to every call.
+ */
+#define QHEA_DP_MAX_RANKS    16
+#define QHEA_DP_HANDLE_BYTES 64
+size_t qhea_dp_buffer_bytes(int64_t n_values, int world);
+/* allocate (fine-grained, zeroed) / free this rank's exchange buffer for `n_values` doubles per rank */
+int qhea_dp_alloc(int64_t n_values, int world, void** buffer /*out: DEVICE*/);
+int qhea_dp_free(void* buffer);
+/* inter-process handle of an exchange buffer (QHEA_DP_HANDLE_BYTES bytes, host), and a peer's buffer mapped from one */
+int qhea_dp_export(void* buffer /*DEVICE*/, void* handle64 /*HOST out*/);
+int qhea_dp_import(const void* handle64 /*HOST*/, void** peer_buffer /*out: DEVICE pointer valid in this process*/);
+int qhea_dp_close(void* peer_buffer);
+/*
+ * out[i] = sum over ranks r = 0..world-1 (in that order) of rank r's local[i], i < n_values; then, if params != NULL,
+ * the Adam update of qhea_adam_step on params[0..n_params) with gradient out[i].  `buffers` is a HOST array of `world`
+ * device pointers: buffers[rank] this rank's own buffer, the others as returned by qhea_dp_import.  `seq` counts the
+ * exchanges on these buffers from 1 and must be the same on every rank for the same step; `local` and `out` may be
+ * the same array.  A rank that does not hear from every other rank within `timeout_ms` writes NaN to `out`, skips the
+ * update and raises the error that qhea_dp_status reports.
+ */
+int qhea_dp_allreduce_adam(int rank, int world, void* const* buffers /*HOST array of DEVICE pointers*/,
+                           int64_t n_values, int64_t seq, const double* local /*DEVICE*/, double* out /*DEVICE*/,
+                           int64_t n_params, double* params /*DEVICE or NULL*/, double* exp_avg, double* exp_avg_sq,
+                           int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay,
+                           double timeout_ms, void* stream);
+/* waits for `stream`; QHEA_EEXCHANGE if an exchange on this buffer timed out since the last call (and clears it) */
+int qhea_dp_status(void* buffer /*DEVICE: this rank's own*/, void* stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,9 @@ LIB_PATH = os.environ.get('QHEA_LIB') or os.path.join(_HERE, 'libquanonet_hea.so
 EXPORTS = ['qhea_version', 'qhea_strerror', 'qhea_device_count', 'qhea_workspace_bytes',
            'qhea_forward', 'qhea_backward', 'qhea_model_param_count', 'qhea_model_workspace_bytes',
            'qhea_model_forward', 'qhea_model_loss_grad', 'qhea_model_train_step', 'qhea_profile_next_circuit_kernel',
-           'qhea_adam_step', 'qhea_set_backward_variant', 'qhea_check_status']
+           'qhea_adam_step', 'qhea_set_backward_variant', 'qhea_check_status',
+           'qhea_dp_buffer_bytes', 'qhea_dp_alloc', 'qhea_dp_free', 'qhea_dp_export', 'qhea_dp_import', 'qhea_dp_close',
+           'qhea_dp_allreduce_adam', 'qhea_dp_status']
 
 
 class ModelDesc(ctypes.Structure):
@@ -28,7 +30,7 @@ class ModelDesc(ctypes.Structure):
 
 
 MODEL_QUANONET, MODEL_HEAQNN = 0, 1
-MIN_LIB_VERSION = 410           # 0.4.1: workspace header, qhea_check_status, qhea_set_backward_variant incl. QHEA_BWD_ZTRI2
+MIN_LIB_VERSION = 420           # 0.4.2: + the data-parallel exchange (qhea_dp_*)
 BWD_VARIANTS = {'auto': 0, 'packed': 1, 'pair': 2, 'tri': 3, 'ztri': 4, 'zpacked': 5, 'ztri2': 6}
 PAULI = {'Z': 0, 'X': 1, 'Y': 2}
 
@@ -62,7 +64,7 @@ def load():
     lib.qhea_version.restype = ctypes.c_int
     if lib.qhea_version() < MIN_LIB_VERSION:
         raise QheaError(f"{LIB_PATH} is version {lib.qhea_version()}, this binding needs >= {MIN_LIB_VERSION} "
-                        f"(the workspace gained a status header): rebuild it")
+                        f"(the data-parallel exchange entry points): rebuild it")
     vp, dp = ctypes.c_void_p, ctypes.c_void_p
     i32p = ctypes.POINTER(ctypes.c_int32)
     lib.qhea_version.restype = ctypes.c_int
@@ -88,6 +90,26 @@ def load():
     lib.qhea_adam_step.argtypes = [ctypes.c_int64, dp, dp, dp, dp, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
                                    ctypes.c_double, ctypes.c_double, ctypes.c_double, vp]
     mdp = ctypes.POINTER(ModelDesc)
+    vpp = ctypes.POINTER(ctypes.c_void_p)
+    lib.qhea_dp_buffer_bytes.restype = ctypes.c_size_t
+    lib.qhea_dp_buffer_bytes.argtypes = [ctypes.c_int64, ctypes.c_int]
+    lib.qhea_dp_alloc.restype = ctypes.c_int
+    lib.qhea_dp_alloc.argtypes = [ctypes.c_int64, ctypes.c_int, vpp]
+    lib.qhea_dp_free.restype = ctypes.c_int
+    lib.qhea_dp_free.argtypes = [vp]
+    lib.qhea_dp_export.restype = ctypes.c_int
+    lib.qhea_dp_export.argtypes = [vp, ctypes.c_char_p]
+    lib.qhea_dp_import.restype = ctypes.c_int
+    lib.qhea_dp_import.argtypes = [ctypes.c_char_p, vpp]
+    lib.qhea_dp_close.restype = ctypes.c_int
+    lib.qhea_dp_close.argtypes = [vp]
+    lib.qhea_dp_allreduce_adam.restype = ctypes.c_int
+    lib.qhea_dp_allreduce_adam.argtypes = [ctypes.c_int, ctypes.c_int, vpp, ctypes.c_int64, ctypes.c_int64, dp, dp,
+                                           ctypes.c_int64, dp, dp, dp, ctypes.c_int64, ctypes.c_double,
+                                           ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_double, vp]
+    lib.qhea_dp_status.restype = ctypes.c_int
+    lib.qhea_dp_status.argtypes = [vp, vp]
     lib.qhea_model_param_count.restype = ctypes.c_int64
     lib.qhea_model_param_count.argtypes = [mdp]
     lib.qhea_model_workspace_bytes.restype = ctypes.c_size_t
@@ -337,3 +359,69 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.9
                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                    _stream(params.device))
     _check(rc, 'qhea_adam_step')
+
+
+# ---- data-parallel exchange (include/quanonet_hea.h: qhea_dp_*) -------------------------------------------------
+DP_MAX_RANKS, DP_HANDLE_BYTES = 16, 64
+
+
+def dp_alloc(n_values, world, device):
+    """This rank's exchange buffer (fine-grained device memory owned by the caller): its device address."""
+    p = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        _check(load().qhea_dp_alloc(int(n_values), int(world), ctypes.byref(p)), 'qhea_dp_alloc')
+    return p.value
+
+
+def dp_free(buf, device):
+    with torch.cuda.device(device):
+        _check(load().qhea_dp_free(buf), 'qhea_dp_free')
+
+
+def dp_export(buf, device):
+    h = ctypes.create_string_buffer(DP_HANDLE_BYTES)
+    with torch.cuda.device(device):
+        _check(load().qhea_dp_export(buf, h), 'qhea_dp_export')
+    return h.raw
+
+
+def dp_import(handle, device):
+    p = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        _check(load().qhea_dp_import(bytes(handle), ctypes.byref(p)), 'qhea_dp_import')
+    return p.value
+
+
+def dp_close(peer_buf, device):
+    with torch.cuda.device(device):
+        _check(load().qhea_dp_close(peer_buf), 'qhea_dp_close')
+
+
+def dp_allreduce_adam(rank, world, buffers, seq, local, out, params=None, exp_avg=None, exp_avg_sq=None, step=1,
+                      lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, timeout_ms=5000.0):
+    """out = sum over ranks (in rank order) of every rank's `local`; Adam on `params` with out[:params.numel()]."""
+    _dev_f64(local, 'local'); _dev_f64(out, 'out')
+    n = local.numel()
+    if out.numel() != n:
+        raise QheaError("dp_allreduce_adam: local and out differ in size")
+    npar = 0
+    if params is not None:
+        for t, nm in ((params, 'params'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
+            _dev_f64(t, nm)
+        npar = params.numel()
+        if npar > n or exp_avg.numel() != npar or exp_avg_sq.numel() != npar:
+            raise QheaError("dp_allreduce_adam: buffer sizes do not match the parameter vector")
+    arr = (ctypes.c_void_p * world)(*buffers)
+    with torch.cuda.device(local.device):
+        rc = load().qhea_dp_allreduce_adam(
+            int(rank), int(world), arr, n, int(seq), _ptr(local), _ptr(out), npar,
+            _ptr(params) if params is not None else None, _ptr(exp_avg) if params is not None else None,
+            _ptr(exp_avg_sq) if params is not None else None, int(step), float(lr), float(beta1), float(beta2),
+            float(eps), float(weight_decay), float(timeout_ms), _stream(local.device))
+    _check(rc, 'qhea_dp_allreduce_adam')
+
+
+def dp_status(buf, device):
+    """Waits for the device's current stream; raises QheaError(QHEA_EEXCHANGE) if an exchange timed out."""
+    with torch.cuda.device(device):
+        _check(load().qhea_dp_status(buf, _stream(device)), 'qhea_dp_status')

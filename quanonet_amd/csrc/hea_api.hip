@@ -6,6 +6,7 @@
 
 #include "hea_device.hpp"
 #include "hea_zyz.hpp"
+#include "hea_adam.hpp"
 
 namespace qhea {
 
@@ -237,26 +238,6 @@ __device__ __forceinline__ double slice_sum(const double* __restrict__ p, long r
     }
     for (int i = 0; r < rows; r += nslices, q += step, ++i) a[i] += *q;
     return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-}
-
-// One Adam update (torch.optim.Adam arithmetic) of element i.  Shared by adam_kernel and by the reduce kernel of
-// qhea_model_train_step, where the thread that finishes a gradient applies it at once.
-struct AdamArgs {
-    double* p; double* m; double* v;           // p == nullptr: no update (plain qhea_model_loss_grad)
-    double lr_over_bc1, inv_sqrt_bc2, b1, b2, eps, wd;
-};
-// (pi, m0, v0 = the element's current parameter and moments: callers that know early which element they will update
-// load them BEFORE their long reduction, so that the update does not add a dependent memory round trip at the end)
-__device__ __forceinline__ void adam_update_pre(const AdamArgs& a, long i, double gi, double pi, double m0, double v0) {
-    if (a.wd != 0.0) gi += a.wd * pi;
-    const double mi = a.b1 * m0 + (1.0 - a.b1) * gi;             // torch: exp_avg.lerp_(grad, 1 - beta1)
-    const double vi = a.b2 * v0 + (1.0 - a.b2) * gi * gi;        //        exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    a.m[i] = mi; a.v[i] = vi;
-    const double denom = sqrt(vi) * a.inv_sqrt_bc2 + a.eps;
-    a.p[i] = pi - a.lr_over_bc1 * (mi / denom);
-}
-__device__ __forceinline__ void adam_update(const AdamArgs& a, long i, double gi) {
-    adam_update_pre(a, i, gi, a.p[i], a.m[i], a.v[i]);
 }
 
 // grad_w[s,{0,1,2},q] from the per-wave (X,Y,Z) partial sums (column sums over waves of partial[wave][s][kw]).
@@ -850,7 +831,7 @@ using namespace qhea;
 
 extern "C" {
 
-int qhea_version(void) { return 410; }
+int qhea_version(void) { return 420; }
 
 const char* qhea_strerror(int code) {
     switch (code) {
@@ -861,6 +842,7 @@ const char* qhea_strerror(int code) {
         case QHEA_ELAUNCH: return "HIP launch/runtime failure";
         case QHEA_ENODEVICE: return "no usable HIP device";
         case QHEA_EPIPELINE: return "a pipelined backward kernel overran a hand-off wait: results of that call are invalid";
+        case QHEA_EEXCHANGE: return "a data-parallel exchange did not hear from every rank in time: that step's update was skipped";
         default: return "unknown error";
     }
 }

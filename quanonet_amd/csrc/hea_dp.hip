@@ -1,0 +1,204 @@
+// hea_dp.hip -- data-parallel gradient exchange without a collective library call on the step's critical path.
+//
+// The data-parallel training step sums ONE flat fp64 buffer [gradients | sse | sum y^2] over the ranks
+// (19 KB at Q5, 46 KB at Q12) and applies the same Adam update everywhere.  Through RCCL that is a collective launch
+// (13-14 us on the device at world size 1 before any link latency, profiles/r02_allreduce_cost_world1_rccl.json) plus
+// a separate Adam launch, on a step of ~100 us.  Here it is ONE one-workgroup kernel per rank:
+//
+//   publish   every rank writes its buffer into slot [parity][rank] of EVERY rank's exchange buffer (peer buffers are
+//             mapped through hipIpc; write-through stores at system scope), drains them, and then
+//             sets flag[rank] = seq in every rank's header (system-scope release);
+//   collect   it waits until the `world` flags in its OWN header have reached seq (system-scope acquire polls with a
+//             wall-clock bound), sums the `world` slots of its own buffer IN RANK ORDER -- every rank adds the same
+//             numbers in the same order, so the replicas stay bitwise identical and runs are reproducible -- writes
+//             the sums back and applies Adam to the parameters.
+//
+// Exchange buffers are fine-grained device memory the library allocates (hipExtMallocWithFlags: hipMalloc'ed memory is
+// cached in the owner's L2, which remote writes do not pass through).  Two slot sets alternate with the parity of seq:
+// a rank can be at most one exchange ahead of the slowest rank (its next collect needs everybody's next flag, which a
+// rank only sets after it has finished reading the previous slots), so seq + 1 never overwrites what a peer still reads.
+// A wait that overruns its bound poisons the output with NaN, skips the Adam update and raises an error word that
+// qhea_dp_status reports -- it never computes through a missing contribution.
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "hea_adam.hpp"
+#include "quanonet_hea.h"
+
+namespace qhea {
+namespace {
+
+constexpr int kDpThreads = 1024;
+constexpr size_t kDpHeaderBytes = 256;
+
+struct DpHeader {
+    unsigned long long flag[QHEA_DP_MAX_RANKS];      // flag[r] = seq of the last exchange rank r has published here
+    unsigned int error;                              // bit 0: a collect wait overran its bound
+};
+static_assert(sizeof(DpHeader) <= kDpHeaderBytes, "header");
+
+__host__ __device__ inline long padded_values(long n) { return (n + 1) & ~1L; }
+__host__ __device__ inline size_t dp_bytes(long n, int world) {
+    return kDpHeaderBytes + (size_t)2 * world * padded_values(n) * sizeof(double);
+}
+__device__ __forceinline__ double* slot(char* buf, int parity, int world, int r, long npad) {
+    return reinterpret_cast<double*>(buf + kDpHeaderBytes) + ((long)parity * world + r) * npad;
+}
+
+struct DpArgs {
+    char* bufs[QHEA_DP_MAX_RANKS];                   // every rank's exchange buffer as mapped in THIS process
+    int rank, world;
+    long n, n_adam;                                  // values exchanged; the first n_adam of them are parameters' gradients
+    unsigned long long seq;
+    const double* local;
+    double* out;
+    AdamArgs adam;
+    long long timeout_ticks;                         // of wall_clock64() (100 MHz)
+};
+
+__global__ __launch_bounds__(kDpThreads) void dp_exchange_kernel(DpArgs a) {
+    const int tid = threadIdx.x, parity = (int)(a.seq & 1);
+    const long npad = padded_values(a.n);
+    __shared__ int failed;
+    if (tid == 0) failed = 0;
+    // ---- publish: this rank's values into slot [parity][rank] of every rank's buffer (own included)
+    for (long i = tid; i < a.n; i += kDpThreads) {
+        const double v = a.local[i];
+        for (int p = 0; p < a.world; ++p)
+            __hip_atomic_store(slot(a.bufs[p], parity, a.world, a.rank, npad) + i, v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: every store above has left this device
+    __syncthreads();
+    if (tid < a.world)
+        __hip_atomic_store(&reinterpret_cast<DpHeader*>(a.bufs[tid])->flag[a.rank], a.seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- collect: wait for everybody's flag in the own header
+    char* own = a.bufs[a.rank];
+    if (tid < a.world) {
+        const unsigned long long* f = &reinterpret_cast<DpHeader*>(own)->flag[tid];
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+            if (wall_clock64() - t0 > a.timeout_ticks) { failed = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    if (failed) {
+        if (tid == 0) atomicOr(&reinterpret_cast<DpHeader*>(own)->error, 1u);
+        for (long i = tid; i < a.n; i += kDpThreads) a.out[i] = std::numeric_limits<double>::quiet_NaN();
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    for (long i = tid; i < a.n; i += kDpThreads) {
+        double s = 0.0;
+        for (int r = 0; r < a.world; ++r)                    // rank order on every rank: bitwise identical replicas
+            s += __hip_atomic_load(slot(own, parity, a.world, r, npad) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        a.out[i] = s;
+        if (a.adam.p && i < a.n_adam) adam_update(a.adam, i, s);
+    }
+}
+
+}  // namespace
+}  // namespace qhea
+
+using namespace qhea;
+
+extern "C" {
+
+size_t qhea_dp_buffer_bytes(int64_t n_values, int world) {
+    if (n_values < 1 || world < 1 || world > QHEA_DP_MAX_RANKS) return 0;
+    return dp_bytes((long)n_values, world);
+}
+
+int qhea_dp_alloc(int64_t n_values, int world, void** buffer) {
+    if (!buffer) return QHEA_EINVAL;
+    *buffer = nullptr;
+    const size_t bytes = qhea_dp_buffer_bytes(n_values, world);
+    if (bytes == 0) return QHEA_EINVAL;
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            return QHEA_ELAUNCH;
+        }
+    }
+    if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(p);
+        return QHEA_ELAUNCH;
+    }
+    *buffer = p;
+    return QHEA_OK;
+}
+
+int qhea_dp_free(void* buffer) {
+    if (!buffer) return QHEA_OK;
+    return hipFree(buffer) == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+}
+
+int qhea_dp_export(void* buffer, void* handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == QHEA_DP_HANDLE_BYTES, "handle size");
+    if (!buffer || !handle64) return QHEA_EINVAL;
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, buffer) != hipSuccess) { (void)hipGetLastError(); return QHEA_ELAUNCH; }
+    std::memcpy(handle64, &h, sizeof h);
+    return QHEA_OK;
+}
+
+int qhea_dp_import(const void* handle64, void** peer_buffer) {
+    if (!handle64 || !peer_buffer) return QHEA_EINVAL;
+    *peer_buffer = nullptr;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle64, sizeof h);
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return QHEA_ELAUNCH; }
+    *peer_buffer = p;
+    return QHEA_OK;
+}
+
+int qhea_dp_close(void* peer_buffer) {
+    if (!peer_buffer) return QHEA_OK;
+    return hipIpcCloseMemHandle(peer_buffer) == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+}
+
+int qhea_dp_allreduce_adam(int rank, int world, void* const* buffers, int64_t n_values, int64_t seq,
+                           const double* local, double* out, int64_t n_params, double* params, double* exp_avg,
+                           double* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double eps,
+                           double weight_decay, double timeout_ms, void* stream) {
+    if (world < 1 || world > QHEA_DP_MAX_RANKS || rank < 0 || rank >= world || !buffers || n_values < 1 || seq < 1 ||
+        !local || !out || n_params < 0 || n_params > n_values || !(timeout_ms > 0.0))
+        return QHEA_EINVAL;
+    DpArgs a{};
+    for (int r = 0; r < world; ++r) {
+        if (!buffers[r]) return QHEA_EINVAL;
+        a.bufs[r] = static_cast<char*>(buffers[r]);
+    }
+    a.rank = rank; a.world = world; a.n = (long)n_values; a.n_adam = (long)n_params;
+    a.seq = (unsigned long long)seq; a.local = local; a.out = out;
+    a.timeout_ticks = (long long)(timeout_ms * 1e5);         // wall_clock64: 100 MHz
+    if (params) {
+        if (!exp_avg || !exp_avg_sq || step < 1) return QHEA_EINVAL;
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        a.adam = AdamArgs{params, exp_avg, exp_avg_sq, lr / bc1, 1.0 / sqrt(bc2), beta1, beta2, eps, weight_decay};
+    }
+    hipLaunchKernelGGL(dp_exchange_kernel, dim3(1), dim3(kDpThreads), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+}
+
+int qhea_dp_status(void* buffer, void* stream) {
+    if (!buffer) return QHEA_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned int err = 0;
+    unsigned int* dev = &static_cast<DpHeader*>(buffer)->error;
+    if (hipMemcpyAsync(&err, dev, sizeof err, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return QHEA_ELAUNCH;
+    if (err == 0) return QHEA_OK;
+    (void)hipMemsetAsync(dev, 0, sizeof err, st);
+    (void)hipStreamSynchronize(st);
+    return QHEA_EEXCHANGE;
+}
+
+}  // extern "C"

@@ -3,7 +3,8 @@ Training loop for QuanONetPT / HEAQNNPT on the HIP quantum layer: host-side mirr
 reference's ``solvers/solver_pt.py`` (PTSolver) plus the data-parallel step the reference lacks.
 
 * ``DataParallelTrainer``: one training step = forward -> MSE -> in-kernel adjoint backward ->
-  ONE all-reduce (SUM) of a flat fp64 buffer [all gradients | sse | sum y^2] -> Adam.
+  ONE sum over the ranks of a flat fp64 buffer [all gradients | sse | sum y^2] -> Adam (``PeerExchange``: both in
+  one kernel over peer-mapped buffers; ``dist.all_reduce`` + an Adam launch where that is not available).
   Each rank's loss is ``sum((pred-y)^2) / global_batch`` so that a plain SUM reproduces the
   gradient of ``MSELoss(mean)`` over the global batch (solver_pt.py:232-236), also for uneven
   shards.  The two logging scalars ride in the same buffer, removing the reference's two
@@ -100,6 +101,118 @@ class FlatAdam(torch.optim.Optimizer):
             self.exp_avg_sq.copy_(fs['exp_avg_sq'])
 
 
+class PeerExchange:
+    """
+    The data-parallel step's gradient sum + Adam update as ONE kernel per rank over peer-mapped exchange buffers
+    (include/quanonet_hea.h: qhea_dp_*, csrc/hea_dp.hip) instead of ``dist.all_reduce`` + a separate Adam launch.
+
+    Set-up uses the process group only for hand-shakes: the 64-byte hipIpc handles travel by ``all_gather_object``,
+    every rank maps the others' buffers, and a three-round self-check (both slot parities, slot reuse) is compared with
+    the analytic sum.  ``create`` returns None -- on EVERY rank, the outcome is agreed by an all-reduce -- when any
+    rank could not map a buffer or saw a wrong sum; the trainer then keeps the RCCL all-reduce.  ``QHEA_DP_EXCHANGE=rccl``
+    switches the peer path off.
+    """
+
+    def __init__(self, dist, rank, world, n_values, device, timeout_ms=5000.0):
+        self.dist, self.rank, self.world, self.n, self.device = dist, rank, world, int(n_values), device
+        self.timeout_ms = float(timeout_ms)
+        self.seq = 0
+        self.own = None
+        self.bufs = [None] * world
+
+    @classmethod
+    def create(cls, dist, rank, world, n_values, device, log=None):
+        from . import _lib
+        say = log if (log is not None and rank == 0) else (lambda *a, **k: None)
+        if world < 2 or world > _lib.DP_MAX_RANKS or device.type != 'cuda':
+            return None
+        if os.environ.get('QHEA_DP_EXCHANGE', 'peer').lower() in ('rccl', 'nccl', 'off', '0'):
+            return None
+        self = cls(dist, rank, world, n_values, device)
+        ok = 1
+        handle = None
+        try:
+            self.own = _lib.dp_alloc(self.n, world, device)
+            handle = _lib.dp_export(self.own, device)
+        except _lib.QheaError:
+            ok = 0
+        handles = [None] * world
+        dist.all_gather_object(handles, handle)
+        if ok and all(h is not None for h in handles):
+            self.bufs[rank] = self.own
+            try:
+                for r in range(world):
+                    if r != rank:
+                        self.bufs[r] = _lib.dp_import(handles[r], device)
+            except _lib.QheaError:
+                ok = 0
+        else:
+            ok = 0
+        if not self._agree(ok):
+            say("data-parallel exchange: peer buffers could not be mapped on every rank -> RCCL all-reduce")
+            self.close()
+            return None
+        if not self._agree(self._self_check()):
+            say("data-parallel exchange: self-check failed -> RCCL all-reduce")
+            self.close()
+            return None
+        say(f"data-parallel exchange: peer-mapped buffers, {world} ranks, {self.n} values")
+        return self
+
+    def _agree(self, ok):
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def _self_check(self):
+        from . import _lib
+        good = True
+        base = torch.arange(1, self.n + 1, dtype=torch.float64, device=self.device) * 1e-3
+        for rnd in range(3):
+            local = base * (self.rank + 1) + rnd
+            out = torch.empty_like(local)
+            self.seq += 1
+            _lib.dp_allreduce_adam(self.rank, self.world, self.bufs, self.seq, local, out, timeout_ms=2000.0)
+            try:
+                _lib.dp_status(self.own, self.device)
+            except _lib.QheaError:
+                good = False
+            want = base * (self.world * (self.world + 1) / 2) + rnd * self.world
+            good = good and bool(torch.allclose(out, want, rtol=1e-13, atol=0.0))
+        return good
+
+    def allreduce_adam(self, flat, pflat, opt):
+        """flat <- sum over ranks of flat (rank order); FlatAdam `opt`'s update of pflat with it; one launch."""
+        from . import _lib
+        g = opt.param_groups[0]
+        opt.t += 1
+        self.seq += 1
+        _lib.dp_allreduce_adam(self.rank, self.world, self.bufs, self.seq, flat, flat, pflat, opt.exp_avg,
+                               opt.exp_avg_sq, opt.t, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
+                               g['weight_decay'], timeout_ms=self.timeout_ms)
+
+    def check_status(self):
+        from . import _lib
+        _lib.dp_status(self.own, self.device)
+
+    def close(self):
+        from . import _lib
+        for r, b in enumerate(self.bufs):
+            if b is not None and r != self.rank:
+                try:
+                    _lib.dp_close(b, self.device)
+                except _lib.QheaError:
+                    pass
+        self.bufs = [None] * self.world
+        if self.own is not None:
+            try:
+                self.dist.barrier()                    # nobody still maps the buffer that is about to be freed
+                _lib.dp_free(self.own, self.device)
+            except Exception:
+                pass
+            self.own = None
+
+
 class DataParallelTrainer:
     """
     fused='auto': when the model is one of this package's QuanONetPT / HEAQNNPT (fp64, on a HIP
@@ -109,7 +222,7 @@ class DataParallelTrainer:
     """
 
     def __init__(self, model, lr=1e-4, world_size=1, dist=None, optimizer='adam', optimizer_kwargs=None,
-                 fused='auto'):
+                 fused='auto', peer_exchange=True, log=None):
         self.model = model
         self.world = int(world_size)
         self.dist = dist
@@ -151,8 +264,11 @@ class DataParallelTrainer:
             if cls in (torch.optim.Adam, torch.optim.AdamW) and p0.is_cuda and 'fused' not in kw:
                 kw['fused'] = True
             self.optimizer = cls(self.params, lr=lr, **kw)
+        self.peer = None
         if self.world > 1:
             self.broadcast_parameters()
+            if isinstance(self.optimizer, FlatAdam) and peer_exchange:
+                self.peer = PeerExchange.create(dist, dist.get_rank(), self.world, self.numel + 2, p0.device, log=log)
 
     def broadcast_parameters(self):
         self.dist.broadcast(self.pflat, src=0)
@@ -202,6 +318,10 @@ class DataParallelTrainer:
                                   ham_diag=self._ham_diag())
             return self.flat
         self.loss_and_grad(*batch, global_batch=global_batch)
+        if self.peer is not None:
+            # sum over the ranks' peer-mapped buffers + Adam in ONE launch (csrc/hea_dp.hip)
+            self.peer.allreduce_adam(self.flat, self.pflat, self.optimizer)
+            return self.flat
         if self.world > 1:
             self.dist.all_reduce(self.flat)            # SUM; one latency-bound message (19 KB at Q5)
         self.optimizer.step()
@@ -218,6 +338,8 @@ class DataParallelTrainer:
         if self.pflat.is_cuda:
             from . import _lib
             _lib.check_status(self.pflat.device)
+            if self.peer is not None:
+                self.peer.check_status()
 
 
 class PTSolver:
@@ -245,7 +367,9 @@ class PTSolver:
         self.model = (model if model is not None else self._create_model()).to(self.device)
         self.trainer = DataParallelTrainer(self.model, lr=config['learning_rate'], world_size=world_size,
                                            dist=dist, optimizer=config.get('optimizer', 'adam'),
-                                           optimizer_kwargs=config.get('optimizer_kwargs', {}))
+                                           optimizer_kwargs=config.get('optimizer_kwargs', {}),
+                                           peer_exchange=str(config.get('dp_exchange', 'peer')).lower() == 'peer',
+                                           log=self.log)
         self.lr_scheduler = self._build_scheduler()
         self.best_loss = float('inf')
         self.best_model_path = None
