@@ -1337,7 +1337,6 @@ __device__ __forceinline__ void zpacked_body(const ZBwdArgs& a, int wib, int lan
     }
     bs.template step<-1>(nb);
     bs.load_records(bs.slot(nb - 1));
-    int sub = a.blk;
     const double2* cs_b = csrow + (long)(nb - 1) * N;             // chunk of the block at hand (every block has enc = n)
     bs.load_cs(cs_b, 0);
     // The workgroup's four waves walk the blocks in step (one barrier per block, BlockStream<SHARED>), so their gradient sums
@@ -1371,7 +1370,6 @@ __device__ __forceinline__ void zpacked_body(const ZBwdArgs& a, int wib, int lan
             pr[0] = lane_gather(pr[0], ring_rev); pi[0] = lane_gather(pi[0], ring_rev);
             lr[0] = lane_gather(lr[0], ring_rev); li[0] = lane_gather(li[0], ring_rev);
             if (s == LD - 1) bs.template ahead_rel<-(kBDist + 1)>(sl, bl);
-            --sub;
             double acc3[C::KW];
 #pragma unroll
             for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
