@@ -282,16 +282,23 @@ class DataParallelTrainer:
         q = getattr(self.model, 'quantum_layer', None)
         return q.ham_diag if (q is not None and getattr(q, 'use_full_ham', False)) else None
 
-    def loss_and_grad(self, *batch, global_batch=None):
-        """Fill self.flat with this shard's [gradients | sse | sum y^2] (no collective, no update)."""
+    @property
+    def accepts_out(self):
+        """Whether train_step can leave [gradients | sse | sum y^2] in a caller's buffer instead of self.flat (the fused
+        model-level path with the flat Adam: nothing reads the parameters' .grad views there)."""
+        return self.desc is not None and isinstance(self.optimizer, FlatAdam)
+
+    def loss_and_grad(self, *batch, global_batch=None, out=None):
+        """Fill self.flat (or `out`, see accepts_out) with this shard's [gradients | sse | sum y^2] (no collective, no
+        update)."""
         *inputs, y = batch
         gb = float(global_batch if global_batch is not None else y.shape[0] * self.world)
         if self.desc is not None:
             from . import _lib
             branch = inputs[0]
             trunk = inputs[1] if len(inputs) > 1 else None
-            _lib.model_loss_grad(self.desc, branch, trunk, y.reshape(-1), self.pflat, 1.0 / gb, self.flat,
-                                 ham_diag=self._ham_diag())
+            _lib.model_loss_grad(self.desc, branch, trunk, y.reshape(-1), self.pflat, 1.0 / gb,
+                                 self.flat if out is None else out, ham_diag=self._ham_diag())
         else:
             self.flat.zero_()
             pred = self._forward(inputs)
@@ -303,8 +310,13 @@ class DataParallelTrainer:
                 self.flat[self.numel + 1] = (y * y).sum()
         return self.flat
 
-    def train_step(self, *batch, global_batch=None):
-        """batch = (branch, trunk, y) or (x, y): this rank's shard.  Returns the flat buffer (device)."""
+    def train_step(self, *batch, global_batch=None, out=None):
+        """batch = (branch, trunk, y) or (x, y): this rank's shard.  Returns the flat buffer (device): self.flat, or
+        `out` -- a caller's [numel + 2] fp64 buffer, honoured where accepts_out says so (PTSolver hands in one row per
+        step of an epoch, so that the two logging scalars of every step stay on the device without a copy)."""
+        if out is not None and not self.accepts_out:
+            out = None
+        flat = self.flat if out is None else out
         if self.world == 1 and self.desc is not None and isinstance(self.optimizer, FlatAdam):
             # single device: loss, gradients and the Adam update in three launches (qhea_model_train_step)
             from . import _lib
@@ -313,19 +325,21 @@ class DataParallelTrainer:
             opt, g = self.optimizer, self.optimizer.param_groups[0]
             opt.t += 1
             _lib.model_train_step(self.desc, inputs[0], inputs[1] if len(inputs) > 1 else None, y.reshape(-1),
-                                  self.pflat, 1.0 / gb, self.flat, opt.exp_avg, opt.exp_avg_sq, opt.t, g['lr'],
+                                  self.pflat, 1.0 / gb, flat, opt.exp_avg, opt.exp_avg_sq, opt.t, g['lr'],
                                   g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'],
                                   ham_diag=self._ham_diag())
-            return self.flat
-        self.loss_and_grad(*batch, global_batch=global_batch)
+            return flat
+        self.loss_and_grad(*batch, global_batch=global_batch, out=out)
         if self.peer is not None:
             # sum over the ranks' peer-mapped buffers + Adam in ONE launch (csrc/hea_dp.hip)
-            self.peer.allreduce_adam(self.flat, self.pflat, self.optimizer)
-            return self.flat
+            self.peer.allreduce_adam(flat, self.pflat, self.optimizer)
+            return flat
         if self.world > 1:
-            self.dist.all_reduce(self.flat)            # SUM; one latency-bound message (19 KB at Q5)
+            self.dist.all_reduce(flat)                 # SUM; one latency-bound message (19 KB at Q5)
+        if out is not None:                            # FlatAdam reads its gradient from self.flat
+            self.flat.copy_(out)
         self.optimizer.step()
-        return self.flat
+        return flat
 
     def loss_scalars(self):
         """(sse, sum y^2) of the last global batch -- forces a device sync; call per epoch, not per step."""
@@ -430,6 +444,25 @@ class PTSolver:
         torch.save(sd, path)
         np.savez(path.replace('.pt', '.npz'), **{k: v.detach().cpu().numpy() for k, v in sd.items()})
 
+    def _stage_epoch(self, n, bs, nb):
+        """
+        One epoch's batch order and this rank's rows of it, gathered ONCE (three gathers per epoch instead of three per
+        step): step i of the reference takes idx[i*bs:(i+1)*bs] (solver_pt.py:226-228), this rank its contiguous shard
+        of that.  Returns (order, row bounds per step, gathered inputs, gathered targets).
+        """
+        idx_dev = self._epoch_permutation(n)
+        bounds, pieces = [0], []
+        for i in range(nb):
+            gb_i = min(bs, n - i * bs)
+            lo, hi = shard_slice(gb_i, self.rank, self.world)
+            pieces.append((i * bs + lo, i * bs + hi))
+            bounds.append(bounds[-1] + hi - lo)
+        if self.world == 1:
+            sel_all = idx_dev
+        else:
+            sel_all = torch.cat([idx_dev[a:b] for a, b in pieces]) if bounds[-1] else idx_dev[:0]
+        return idx_dev, bounds, [t[sel_all] for t in self.train_input], self.train_output[sel_all]
+
     def _epoch_permutation(self, n):
         """
         ``np.random.permutation(n)`` from NumPy's global generator, as the reference draws it (solver_pt.py:220), so a
@@ -456,28 +489,38 @@ class PTSolver:
             history['loss_steps'], history['indices'] = [], []
         os.makedirs(self.out_dir, exist_ok=True)
         self.best_model_path = os.path.join(self.out_dir, 'best_model.pt')
+        staged = self._stage_epoch(n, bs, nb) if epochs > 0 else None
         for epoch in range(epochs):
             self.model.train()
-            idx_dev = self._epoch_permutation(n)
-            stats = torch.zeros(3, dtype=torch.float64, device=self.device)   # sum of batch MSE, sse, sum y^2
-            steps = torch.zeros(nb, dtype=torch.float64, device=self.device) if trace else None
+            idx_dev, bounds, ep_inputs, ep_output = staged
+            # (sse, sum y^2) of every global batch stay on the device until the epoch ends.  On the fused path every step
+            # leaves its [gradients | sse | sum y^2] in a row of its own (no copy kernel per step; nb x 19 KB at Q5)
+            nm = self.trainer.numel
+            rows = (torch.zeros(nb, nm + 2, dtype=torch.float64, device=self.device) if self.trainer.accepts_out
+                    else None)
+            tails = rows[:, nm:] if rows is not None else torch.zeros(nb, 2, dtype=torch.float64, device=self.device)
             for i in range(nb):
-                idx = idx_dev[i * bs:(i + 1) * bs]
-                gb = idx.numel()
-                lo, hi = shard_slice(gb, self.rank, self.world)
-                sel = idx[lo:hi]
-                flat = self.trainer.train_step(*[t[sel] for t in self.train_input], self.train_output[sel],
-                                               global_batch=gb)
-                tail = flat[self.trainer.numel:]
-                stats[0] += tail[0] / gb
-                stats[1] += tail[0]
-                stats[2] += tail[1]
-                if trace:
-                    steps[i] = tail[0] / gb
-            s = stats.tolist()                                  # one host sync per epoch
+                a, b = bounds[i], bounds[i + 1]
+                gb = min(bs, n - i * bs)
+                flat = self.trainer.train_step(*[t[a:b] for t in ep_inputs], ep_output[a:b], global_batch=gb,
+                                               out=None if rows is None else rows[i])
+                if rows is None:
+                    tails[i].copy_(flat[nm:])
+            # the next epoch's order and rows are drawn and gathered BEFORE the host waits for this epoch: the draw (a
+            # millisecond of host time at 10^5 rows) and the upload overlap the steps still queued on the device
+            staged = self._stage_epoch(n, bs, nb) if epoch + 1 < epochs else None
+            tl = tails.tolist()                                 # one host sync per epoch
+            s = [0.0, 0.0, 0.0]                                 # sum of batch MSE, sse, sum y^2 -- added in step order
+            step_mse = []
+            for i in range(nb):
+                gb = min(bs, n - i * bs)
+                step_mse.append(tl[i][0] / gb)
+                s[0] += tl[i][0] / gb
+                s[1] += tl[i][0]
+                s[2] += tl[i][1]
             self.trainer.check_status()                         # a kernel-side pipeline failure ends the run here
             if trace:
-                history['loss_steps'].extend(steps.tolist())
+                history['loss_steps'].extend(step_mse)
                 history['indices'].append(idx_dev.cpu().numpy())
             avg_loss = s[0] / nb
             avg_rel = np.sqrt(s[1]) / (np.sqrt(s[2]) + 1e-8)

@@ -101,7 +101,8 @@ def test_exchange_sums_in_rank_order_and_fuses_adam(world):
         np.testing.assert_array_equal(p, res[0][3])              # replicas bitwise identical
 
 
-def _solver_worker(rank, world, port, q, tmp):
+def _solver_worker(rank, world, port, q, tmp, exchange):
+    os.environ['QHEA_DP_EXCHANGE'] = exchange
     dist = _init(rank, world, port)
     from quanonet_amd.solver import PTSolver, set_random_seed
     cfg, data, a, order, seed = H.trajectory_solver_inputs('quanonet_tf', tmp)
@@ -119,12 +120,13 @@ def _solver_worker(rank, world, port, q, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_multi_rank_ptsolver_through_the_peer_exchange_equals_the_trace(world, tmp_path):
+@pytest.mark.parametrize('world,exchange', [(2, 'peer'), (3, 'peer'), (2, 'rccl')])
+def test_multi_rank_ptsolver_through_the_peer_exchange_equals_the_trace(world, exchange, tmp_path):
+    """exchange = 'rccl': the fallback (all_reduce of the step's row + qhea_adam_step) through the same loop."""
     cfg, data, a, order, seed = H.trajectory_solver_inputs('quanonet_tf', str(tmp_path))
-    res = _spawn(_solver_worker, world, extra=(str(tmp_path),))
+    res = _spawn(_solver_worker, world, extra=(str(tmp_path), exchange))
     for rank, used_peer, loss_train, loss_steps, sd in res:
-        assert used_peer, "the data-parallel step fell back to the all-reduce"
+        assert used_peer == (exchange == 'peer'), "the data-parallel step did not take the requested exchange"
         np.testing.assert_allclose(loss_steps, a['step_loss'], rtol=0, atol=1e-9)
         np.testing.assert_allclose(loss_train, a['epoch_loss'], rtol=0, atol=1e-9)
         for k in order:

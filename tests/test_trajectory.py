@@ -124,9 +124,9 @@ def _solver_worker(rank, world, port, q, tmp, n_test):
     taken = []
     orig = s.trainer.train_step
 
-    def spy(*batch, global_batch=None):
+    def spy(*batch, global_batch=None, **kw):
         taken.append((batch[-1].reshape(-1).clone().numpy(), global_batch))
-        return orig(*batch, global_batch=global_batch)
+        return orig(*batch, global_batch=global_batch, **kw)
     s.trainer.train_step = spy
     hist = s.train()
     metrics = s.evaluate(hist)
