@@ -206,7 +206,7 @@ class PeerExchange:
         self.bufs = [None] * self.world
         if self.own is not None:
             try:
-                self.dist.barrier()                    # nobody still maps the buffer that is about to be freed
+                self.dist.barrier()                    # every importer has closed its mapping of the buffer freed next
                 _lib.dp_free(self.own, self.device)
             except Exception:
                 pass
