@@ -398,7 +398,7 @@ int use_tri() {                                   // which pipelined variant whe
     return g_bwd_variant.load(std::memory_order_relaxed) == QHEA_BWD_PAIR ? 0 : 1;   // default: psi / lambda / sigma waves
 }
 bool use_pair(int n, int64_t B) {
-    if (n > 5 || B <= 0 || n == QHEA_EXP_N) return false;
+    if (n > 5 || B <= 0) return false;
     const int v = g_bwd_variant.load(std::memory_order_relaxed);
     if (v == QHEA_BWD_PACKED || v == QHEA_BWD_ZPACKED) return false;
     if (v == QHEA_BWD_PAIR || v == QHEA_BWD_TRI || v == QHEA_BWD_ZTRI || v == QHEA_BWD_ZTRI2) return true;
@@ -431,7 +431,7 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     // second-generation kernels for n <= 5 (hea_zyz.hpp): the default when the shape is eligible; the first-generation
     // variants stay selectable (qhea_set_backward_variant) and take over for shapes whose (cos, sin) table exceeds LDS
     const int var = g_bwd_variant.load(std::memory_order_relaxed);
-    const bool zok = zyz_eligible(n, sh.E) && n != QHEA_EXP_N &&
+    const bool zok = zyz_eligible(n, sh.E) &&
                      (var == QHEA_BWD_AUTO || var == QHEA_BWD_ZTRI || var == QHEA_BWD_ZTRI2 || var == QHEA_BWD_ZPACKED);
     // Measured at cfg 2's circuit (us per call incl. prep / reduce; first-generation / ZYZ form):
     //   forward   B = 1024 55 / 44,  4096 87 / 89,  16384 236 / 255 with a record ring per wave (22 KB of LDS per wave
@@ -448,7 +448,7 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     L.ztri = zok && L.pair;
     // batches that fill the SIMDs: the one-wave ZYZ kernel for the block-unrolled shapes (B = 16384 at cfg 2's circuit:
     // see DESIGN.md section 3.5), the first-generation packed kernel otherwise
-    const bool zp_ok = zyz_eligible(n, sh.E) && n != QHEA_EXP_N && zyz_fast_ld(sh.runs, n) != 0 && !L.lds_bwd;
+    const bool zp_ok = zyz_eligible(n, sh.E) && zyz_fast_ld(sh.runs, n) != 0 && !L.lds_bwd;
     L.zpacked = zp_ok && ((var == QHEA_BWD_AUTO && !L.pair) || var == QHEA_BWD_ZPACKED);
     if (L.zpacked) {
         L.pair = false; L.ztri = false;

@@ -54,14 +54,9 @@ struct EncSeg {
 };
 struct EncDesc { EncSeg seg[2]; };
 
-// Layout experiment (never shipped): -DQHEA_EXP_N=5 -DQHEA_EXP_LB=4 (or 3) builds the packed
-// kernels of that qubit count with fewer lane bits and 2^(N-LB) amplitudes per lane (more samples per wave, the
-// top qubits' gates in-lane); the pipelined kernels need the all-lane layout and are compiled out of such a build.
-#ifndef QHEA_EXP_N
-#define QHEA_EXP_N 0
-#define QHEA_EXP_LB 0
-#endif
-__host__ __device__ constexpr int lane_bits(int n) { return n == QHEA_EXP_N ? QHEA_EXP_LB : (n < 6 ? n : 6); }
+// lane bits per sample: qubits 0 .. LB-1 live in the lane index, the rest in a per-lane register index.  (Fewer lane bits
+// for n = 5 were measured in round 2 and lose at every BASELINE batch: profiles/r02_layout_sweep.txt)
+__host__ __device__ constexpr int lane_bits(int n) { return n < 6 ? n : 6; }
 
 template <int N>
 struct Cfg {

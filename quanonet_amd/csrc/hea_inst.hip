@@ -29,7 +29,7 @@ void QHEA_CAT(launch_bwd_, QHEA_N)(dim3 grid, hipStream_t st, const BwdArgs& a) 
 }
 
 void QHEA_CAT(launch_bwd_pair_, QHEA_N)(dim3 grid, hipStream_t st, const BwdArgs& a) {
-#if QHEA_N <= 5 && QHEA_N != QHEA_EXP_N
+#if QHEA_N <= 5
     if (a.tri == 1) {
         hipLaunchKernelGGL(bwd_tri_kernel<QHEA_N>, grid, dim3(128 + 64 * kSigmaWaves), 0, st, a.runs, a.B, a.E, a.blk, a.cs, a.gates,
                            a.gates_bytes, a.off, a.co, a.diag, a.pauli, a.g, a.state_in, a.y, a.bias, a.inv_bt, a.out,
@@ -44,7 +44,7 @@ void QHEA_CAT(launch_bwd_pair_, QHEA_N)(dim3 grid, hipStream_t st, const BwdArgs
 #endif
 }
 
-#if QHEA_N <= 5 && QHEA_N != QHEA_EXP_N
+#if QHEA_N <= 5
 void QHEA_CAT(launch_fwd_zyz_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArgs& a) {
     hipLaunchKernelGGL(fwd_zyz_kernel<QHEA_N>, grid, dim3((kWaves + kFwdHelpers) * 64), dyn_lds, st, a);
 }
