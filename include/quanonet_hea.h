@@ -245,6 +245,21 @@ int qhea_model_train_step(const qhea_model_desc* desc, int64_t batch,
                           void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * `n_steps` consecutive qhea_model_train_step calls over CONTIGUOUS rows, issued from one host call: the inner loop of
+ * one epoch (solvers/solver_pt.py:226-241, after the epoch's rows have been gathered in batch order).  Step i takes
+ * rows [row_begin[i], row_begin[i+1]) of branch / trunk / y, weights its residuals with inv_batch_total[i], leaves its
+ * [P+2] buffer (gradients | sse | sum y^2) at grad + i * grad_stride and applies Adam update number first_step + i.
+ * Nothing is synchronised; results are bitwise those of the single calls.  The workspace must fit the largest step.
+ */
+int qhea_model_train_steps(const qhea_model_desc* desc, int64_t n_steps, const int64_t* row_begin /*HOST [n_steps+1]*/,
+                           const double* branch /*DEVICE*/, const double* trunk /*DEVICE or NULL*/,
+                           const double* y /*DEVICE*/, double* params /*DEVICE flat*/, const double* ham_diag,
+                           const double* inv_batch_total /*HOST [n_steps]*/, double* grad /*DEVICE [n_steps][grad_stride]*/,
+                           int64_t grad_stride, double* exp_avg, double* exp_avg_sq, int64_t first_step, double lr,
+                           double beta1, double beta2, double eps, double weight_decay, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/*
  * One Adam update of the flat parameter vector, in place, in ONE launch.  Same arithmetic as
  * torch.optim.Adam (amsgrad=False, maximize=False; the reference's optimizer, solvers/solver_pt.py:149-163):
  *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)

@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get('QHEA_LIB') or os.path.join(_HERE, 'libquanonet_hea.so
 
 EXPORTS = ['qhea_version', 'qhea_strerror', 'qhea_device_count', 'qhea_workspace_bytes',
            'qhea_forward', 'qhea_backward', 'qhea_model_param_count', 'qhea_model_workspace_bytes',
-           'qhea_model_forward', 'qhea_model_loss_grad', 'qhea_model_train_step', 'qhea_profile_next_circuit_kernel',
+           'qhea_model_forward', 'qhea_model_loss_grad', 'qhea_model_train_step', 'qhea_model_train_steps',
+           'qhea_profile_next_circuit_kernel',
            'qhea_adam_step', 'qhea_set_backward_variant', 'qhea_check_status',
            'qhea_dp_buffer_bytes', 'qhea_dp_alloc', 'qhea_dp_free', 'qhea_dp_export', 'qhea_dp_import', 'qhea_dp_close',
            'qhea_dp_allreduce_adam', 'qhea_dp_status']
@@ -90,6 +91,12 @@ def load():
     lib.qhea_adam_step.argtypes = [ctypes.c_int64, dp, dp, dp, dp, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
                                    ctypes.c_double, ctypes.c_double, ctypes.c_double, vp]
     mdp = ctypes.POINTER(ModelDesc)
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    f64p = ctypes.POINTER(ctypes.c_double)
+    lib.qhea_model_train_steps.restype = ctypes.c_int
+    lib.qhea_model_train_steps.argtypes = [mdp, ctypes.c_int64, i64p, dp, dp, dp, dp, dp, f64p, dp, ctypes.c_int64, dp, dp,
+                                           ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_double, ctypes.c_double, vp, ctypes.c_size_t, vp]
     vpp = ctypes.POINTER(ctypes.c_void_p)
     lib.qhea_dp_buffer_bytes.restype = ctypes.c_size_t
     lib.qhea_dp_buffer_bytes.argtypes = [ctypes.c_int64, ctypes.c_int]
@@ -338,6 +345,43 @@ def model_train_step(desc, branch, trunk, y, params, inv_batch_total, grad, exp_
                                        _stream(branch.device))
     _check(rc, 'qhea_model_train_step')
     return grad
+
+
+def model_train_steps(desc, bounds, global_batches, branch, trunk, y, params, rows, exp_avg, exp_avg_sq, first_step, lr,
+                      beta1, beta2, eps, weight_decay, ham_diag=None):
+    """
+    One epoch's inner loop in one host call (qhea_model_train_steps): step i trains on rows bounds[i]:bounds[i+1] of the
+    contiguous branch / trunk / y with residual weight 1 / global_batches[i] and leaves [grads | sse | sum y^2] in rows[i].
+    """
+    lib = load()
+    n_steps = len(bounds) - 1
+    if n_steps <= 0:
+        return rows
+    N = branch.shape[0]
+    _dev_f64(branch, 'branch', (N, desc.branch_in))
+    if desc.model == MODEL_QUANONET:
+        _dev_f64(trunk, 'trunk', (N, desc.trunk_in))
+    _dev_f64(y, 'y')
+    for t, nm in ((params, 'params'), (rows, 'rows'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
+        _dev_f64(t, nm)
+    P = params.numel()
+    if y.numel() != N or bounds[-1] > N or len(global_batches) != n_steps:
+        raise QheaError("model_train_steps: row bounds do not match the arrays")
+    if rows.dim() != 2 or rows.shape[0] < n_steps or rows.shape[1] < P + 2 or exp_avg.numel() != P or exp_avg_sq.numel() != P:
+        raise QheaError("model_train_steps: flat vectors have inconsistent lengths")
+    _dev_f64(ham_diag, 'ham_diag', (1 << desc.n_qubits,))
+    biggest = max(bounds[i + 1] - bounds[i] for i in range(n_steps))
+    nbytes = int(lib.qhea_model_workspace_bytes(ctypes.byref(desc), biggest))
+    ws = _workspace(branch.device, nbytes)
+    rb = (ctypes.c_int64 * (n_steps + 1))(*[int(b) for b in bounds])
+    ib = (ctypes.c_double * n_steps)(*[1.0 / float(g) for g in global_batches])
+    with torch.cuda.device(branch.device):
+        rc = lib.qhea_model_train_steps(ctypes.byref(desc), n_steps, rb, _ptr(branch), _ptr(trunk), _ptr(y), _ptr(params),
+                                        _ptr(ham_diag), ib, _ptr(rows), int(rows.stride(0)), _ptr(exp_avg),
+                                        _ptr(exp_avg_sq), int(first_step), float(lr), float(beta1), float(beta2),
+                                        float(eps), float(weight_decay), _ptr(ws), ws.numel(), _stream(branch.device))
+    _check(rc, 'qhea_model_train_steps')
+    return rows
 
 
 def profile_next_circuit_kernel(start_event, stop_event):

@@ -1139,6 +1139,34 @@ int qhea_model_train_step(const qhea_model_desc* desc, int64_t batch, const doub
                                 workspace_bytes, stream, adam);
 }
 
+int qhea_model_train_steps(const qhea_model_desc* desc, int64_t n_steps, const int64_t* row_begin,
+                           const double* branch, const double* trunk, const double* y, double* params,
+                           const double* ham_diag, const double* inv_batch_total, double* grad, int64_t grad_stride,
+                           double* exp_avg, double* exp_avg_sq, int64_t first_step, double lr, double beta1,
+                           double beta2, double eps, double weight_decay, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    if (!desc || n_steps < 0 || !row_begin || !inv_batch_total || !branch || !y || !grad || first_step < 1)
+        return QHEA_EINVAL;
+    ModelInfo mi;
+    const int rc0 = model_info(desc, mi);
+    if (rc0 != QHEA_OK) return rc0;
+    if (grad_stride < qhea_model_param_count(desc) + 2) return QHEA_EINVAL;
+    for (int64_t i = 0; i < n_steps; ++i)
+        if (row_begin[i + 1] <= row_begin[i] || row_begin[i] < 0) return QHEA_EINVAL;
+    const bool has_trunk = desc->model == QHEA_MODEL_QUANONET;
+    if (has_trunk && !trunk) return QHEA_EINVAL;
+    for (int64_t i = 0; i < n_steps; ++i) {
+        const int64_t r0 = row_begin[i], nb = row_begin[i + 1] - r0;
+        const int rc = qhea_model_train_step(desc, nb, branch + r0 * desc->branch_in,
+                                             has_trunk ? trunk + r0 * desc->trunk_in : nullptr, y + r0, params, ham_diag,
+                                             inv_batch_total[i], grad + i * grad_stride, nullptr, exp_avg, exp_avg_sq,
+                                             first_step + i, lr, beta1, beta2, eps, weight_decay, workspace,
+                                             workspace_bytes, stream);
+        if (rc != QHEA_OK) return rc;
+    }
+    return QHEA_OK;
+}
+
 int qhea_adam_step(int64_t n, double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t step,
                    double lr, double beta1, double beta2, double eps, double weight_decay, void* stream) {
     if (n < 0 || step < 1) return QHEA_EINVAL;

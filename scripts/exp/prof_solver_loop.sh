@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_loop
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_loop -- python3 scripts/solver_loop_rate.py 102400 3 > gpurun_out/prof_loop.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_loop -- python3 scripts/solver_loop_rate.py ${LOOP_ARGS:-102400 3} > gpurun_out/prof_loop.log 2>&1
 tail -1 gpurun_out/prof_loop.log
 python3 - <<'PY'
 import csv, glob

@@ -577,3 +577,37 @@ def test_float32_module_like_the_reference(dev):
     for k, p in model.named_parameters():
         assert p.grad.dtype == torch.float32
         np.testing.assert_allclose(p.grad.cpu().numpy().reshape(-1), rg[k].reshape(-1), rtol=0, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_train_steps_from_one_host_call_equal_the_single_steps_bitwise():
+    """qhea_model_train_steps (one epoch's inner loop from one host call) against a loop of qhea_model_train_step:
+    uneven last batch, parameters / Adam state / every step's [grads | sse | sum y^2] row bitwise equal."""
+    from quanonet_amd.models import QuanONetPT
+    from quanonet_amd.solver import DataParallelTrainer
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(5)
+    n, bs = 230, 64                                             # 3 full batches + one of 38 rows
+    branch = torch.tensor(rng.normal(size=(n, 7)), device=dev)
+    trunk = torch.tensor(rng.uniform(size=(n, 2)), device=dev)
+    y = torch.tensor(rng.normal(size=(n, 1)), device=dev)
+    bounds = [0, 64, 128, 192, 230]
+    gbs = [64, 64, 64, 38]
+
+    def make():
+        torch.manual_seed(11)
+        return DataParallelTrainer(QuanONetPT(4, 7, 2, (3, 2, 2, 1), scale_coeff=0.1).double().to(dev), lr=1e-2)
+    a, b = make(), make()
+    assert a.accepts_out
+    rows_a = torch.zeros(4, a.numel + 2, dtype=torch.float64, device=dev)
+    rows_b = torch.zeros_like(rows_a)
+    for i in range(4):
+        lo, hi = bounds[i], bounds[i + 1]
+        a.train_step(branch[lo:hi], trunk[lo:hi], y[lo:hi], global_batch=gbs[i], out=rows_a[i])
+    b.train_steps([branch, trunk], y, bounds, gbs, rows_b)
+    torch.cuda.synchronize()
+    assert torch.equal(rows_a, rows_b)
+    assert torch.equal(a.pflat, b.pflat)
+    assert torch.equal(a.optimizer.exp_avg, b.optimizer.exp_avg) and torch.equal(a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq)
+    assert a.optimizer.t == b.optimizer.t == 4
+    assert float(rows_a[:, a.numel].min()) > 0.0                # every step reported its sse
