@@ -640,11 +640,12 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
     __shared__ double acc[kRedThreads];
     __shared__ double acc2[kRedThreads];
     const int bid = blockIdx.x;
-    const bool poisoned = hdr->status != 0;        // hand-off overrun in the circuit kernel: NaN out, no parameter update
+    // hand-off overrun in the circuit kernel: NaN out, no parameter update.  The word is only USED at the end of each
+    // branch: nothing that is loaded before the sums depends on it, so its round trip overlaps theirs.
+    const unsigned status = hdr->status;
     const double kNaN = std::numeric_limits<double>::quiet_NaN();
-    if (poisoned) adam.p = nullptr;
     if (bid < nb_w) {
-        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, poisoned, gmap, &adam, gm.off_ans);
+        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, status != 0, gmap, &adam, gm.off_ans);
     } else if (bid < nb_w + nb_x) {
         const int j = threadIdx.x % kFreqCols, slice = threadIdx.x / kFreqCols;
         const int e = (bid - nb_w) * kFreqCols + j;
@@ -688,10 +689,11 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         if (slice == 0 && e < E && gm.off_w[si] >= 0) {
             double t0 = 0.0, t1 = 0.0;
             for (int i = 0; i < kFreqSlices; ++i) { t0 += acc[i * kFreqCols + j]; t1 += acc2[i * kFreqCols + j]; }
+            const bool poisoned = status != 0;
             if (poisoned) t0 = t1 = kNaN;
             grad[gm.off_b[si] + ee] = t0;
             grad[gm.off_w[si] + ee] = t1;
-            if (adam.p) { adam_update(adam, gm.off_b[si] + ee, t0); adam_update(adam, gm.off_w[si] + ee, t1); }
+            if (adam.p && !poisoned) { adam_update(adam, gm.off_b[si] + ee, t0); adam_update(adam, gm.off_w[si] + ee, t1); }
         }
     } else {
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -711,12 +713,13 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
             __syncthreads();
         }
         if (threadIdx.x == 0) {
+            const bool poisoned = status != 0;
             grad[gm.off_sse] = poisoned ? kNaN : acc[0];
             grad[gm.off_sse + 1] = red3[0];
             if (gm.off_bias >= 0) {
                 const double gbias = poisoned ? kNaN : 2.0 * inv_bt * acc2[0];
                 grad[gm.off_bias] = gbias;
-                if (adam.p) adam_update(adam, gm.off_bias, gbias);
+                if (adam.p && !poisoned) adam_update(adam, gm.off_bias, gbias);
             }
         }
     }
