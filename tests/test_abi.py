@@ -137,3 +137,46 @@ def test_module_surface_matches_reference_contract(lib):
     from quanonet_amd import _lib
     with pytest.raises(_lib.QheaError):                            # no CPU fallback
         m(torch.zeros(4, 100, dtype=torch.float64), torch.zeros(4, 2, dtype=torch.float64))
+
+
+def test_dp_exchange_argument_validation_without_gpu(lib):
+    """qhea_dp_*: sizes and argument errors are decided on the host before any HIP call."""
+    vp = ctypes.c_void_p
+    assert lib.qhea_dp_buffer_bytes(2403, 8) == 256 + 2 * 8 * 2404 * 8          # header + 2 parities x world x padded values
+    assert lib.qhea_dp_buffer_bytes(2403, 17) == 0                              # QHEA_DP_MAX_RANKS = 16
+    assert lib.qhea_dp_buffer_bytes(0, 2) == 0
+    assert lib.qhea_dp_alloc(0, 2, ctypes.byref(vp())) == -1
+    assert lib.qhea_dp_export(None, None) == -1
+    assert lib.qhea_dp_import(None, None) == -1
+    assert lib.qhea_dp_free(None) == 0 and lib.qhea_dp_close(None) == 0
+    assert lib.qhea_dp_status(None, None) == -1
+    bufs = (vp * 2)(None, None)
+    fake = vp(8)
+    # rank outside the world, missing buffers, seq < 1, more parameters than values
+    args = lambda rank, world, n, seq, npar: lib.qhea_dp_allreduce_adam(rank, world, bufs, n, seq, fake, fake, npar, None,
+                                                                         None, None, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0,
+                                                                         100.0, None)
+    assert args(2, 2, 16, 1, 0) == -1
+    assert args(0, 2, 16, 1, 0) == -1                # buffers[r] == NULL
+    assert args(0, 17, 16, 1, 0) == -1
+    bufs[0] = 8; bufs[1] = 8
+    assert args(0, 2, 16, 0, 0) == -1
+    assert args(0, 2, 16, 1, 17) == -1
+    assert b'exchange' in lib.qhea_strerror(-7)
+
+
+def test_train_steps_argument_validation_without_gpu(lib):
+    from quanonet_amd import _lib
+    desc = _lib.ModelDesc(0, 5, (ctypes.c_int32 * 4)(40, 2, 20, 2), 100, 2, 1, 0, 0.1, 0.0, 1.0)
+    i64 = ctypes.c_int64
+    fake = ctypes.c_void_p(8)
+    ok_rows = (i64 * 3)(0, 4, 8); bad_rows = (i64 * 3)(0, 4, 4)
+    inv = (ctypes.c_double * 2)(0.25, 0.25)
+    call = lambda rows, stride, first: lib.qhea_model_train_steps(ctypes.byref(desc), 2, rows, fake, fake, fake, fake, None,
+                                                                  inv, fake, stride, fake, fake, first, 1e-4, 0.9, 0.999,
+                                                                  1e-8, 0.0, None, 0, None)
+    P = lib.qhea_model_param_count(ctypes.byref(desc))
+    assert P == 2401
+    assert call(bad_rows, P + 2, 1) == -1            # an empty step
+    assert call(ok_rows, P + 1, 1) == -1             # rows too narrow for [grads | sse | sum y^2]
+    assert call(ok_rows, P + 2, 0) == -1             # Adam update count starts at 1
