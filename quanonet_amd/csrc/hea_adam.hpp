@@ -13,13 +13,16 @@ struct AdamArgs {
 };
 // (pi, m0, v0 = the element's current parameter and moments: callers that know early which element they will update
 // load them BEFORE their long reduction, so that the update does not add a dependent memory round trip at the end)
-__device__ __forceinline__ void adam_update_pre(const AdamArgs& a, long i, double gi, double pi, double m0, double v0) {
+// returns the updated parameter
+__device__ __forceinline__ double adam_update_pre(const AdamArgs& a, long i, double gi, double pi, double m0, double v0) {
     if (a.wd != 0.0) gi += a.wd * pi;
     const double mi = a.b1 * m0 + (1.0 - a.b1) * gi;             // torch: exp_avg.lerp_(grad, 1 - beta1)
     const double vi = a.b2 * v0 + (1.0 - a.b2) * gi * gi;        //        exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     a.m[i] = mi; a.v[i] = vi;
     const double denom = sqrt(vi) * a.inv_sqrt_bc2 + a.eps;
-    a.p[i] = pi - a.lr_over_bc1 * (mi / denom);
+    const double pn = pi - a.lr_over_bc1 * (mi / denom);
+    a.p[i] = pn;
+    return pn;
 }
 __device__ __forceinline__ void adam_update(const AdamArgs& a, long i, double gi) {
     adam_update_pre(a, i, gi, a.p[i], a.m[i], a.v[i]);

@@ -137,21 +137,25 @@ __device__ inline LayerInfo decode_layer(const Runs& r, int n, int l) {
 // It also leaves, per ansatz gate, the six numbers the reduce kernel's gradient map needs (cos/sin of b, c and alpha),
 // so that the reduce kernel does not spend five serial sincos per gate on them: gmap[s*n + q] = 8 doubles.
 constexpr int kGmapDoubles = 8;
-__global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, const double* __restrict__ w,
-                                                      char* __restrict__ rec, char* __restrict__ srec,
-                                                      double* __restrict__ gmap, WorkspaceHeader* hdr) {
-    const int l = blockIdx.x, j = threadIdx.x;
-    if (l == 0 && j == 0) header_init(hdr);
+struct PrepShared {
+    GateZ gz[2][QHEA_MAX_QUBITS];           // [0]: this layer's gates, [1]: the previous layer's
+    double2 half[2][3][QHEA_MAX_QUBITS];    // (cos, sin) of the half angles: one sincos per thread, not three in a row
+};
+// Record of layer l by a group of 64 threads (j = index within the group; threads of the block outside every group pass
+// j >= 64 and only join the two barriers).  wfetch(s, k, q) = ansatz angle w[s, k, q]: from global memory in
+// prep_zyz_kernel, from the block's freshly updated values where the reduce kernel writes the next step's records.
+template <class F>
+__device__ __forceinline__ void prep_layer_body(const Runs& runs, int n, int L, int l, int j, F wfetch, char* __restrict__ rec,
+                                                char* __restrict__ srec, double* __restrict__ gmap, PrepShared& sh) {
+    if (j < 0) j = 1 << 30;
     const LayerInfo cur = decode_layer(runs, n, l < L ? l : -1), prev = decode_layer(runs, n, l - 1);
-    __shared__ GateZ gz[2][QHEA_MAX_QUBITS];           // [0]: this layer's gates, [1]: the previous layer's
-    __shared__ double2 half[2][3][QHEA_MAX_QUBITS];    // (cos, sin) of the half angles: one sincos per thread, not three in a row
     if (j < 6 * n) {
         const int which = j / (3 * n), k = (j / n) % 3, q = j % n;
         const LayerInfo& li = which ? prev : cur;
         if (li.kind == 1) {
             double sn, cn;
-            sincos(0.5 * w[(long)li.s * 3 * n + k * n + q], &sn, &cn);
-            half[which][k][q] = make_double2(cn, sn);
+            sincos(0.5 * wfetch(li.s, k, q), &sn, &cn);
+            sh.half[which][k][q] = make_double2(cn, sn);
         }
     }
     __syncthreads();
@@ -159,8 +163,8 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
         const int which = j / n, q = j % n;
         const LayerInfo& li = which ? prev : cur;
         if (li.kind == 1) {
-            const GateZ g = gate_zyz(half[which][0][q], half[which][1][q], half[which][2][q]);
-            gz[which][q] = g;
+            const GateZ g = gate_zyz(sh.half[which][0][q], sh.half[which][1][q], sh.half[which][2][q]);
+            sh.gz[which][q] = g;
             if (which == 0) {
                 const double2 z = cmul(g.u, g.u);                    // e^{-i alpha}
                 double* gm = gmap + ((long)li.s * n + q) * kGmapDoubles;
@@ -185,10 +189,10 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
     if (j < (1 << n)) {
         double2 ph = make_double2(1.0, 0.0);
         if (cur.kind == 1)
-            for (int q = 0; q < n; ++q) ph = cmul(ph, ((j >> q) & 1) ? cconj(gz[0][q].v) : gz[0][q].v);
+            for (int q = 0; q < n; ++q) ph = cmul(ph, ((j >> q) & 1) ? cconj(sh.gz[0][q].v) : sh.gz[0][q].v);
         if (prev.kind == 1) {
             const int h = ring_src_index(n, j);
-            for (int q = 0; q < n; ++q) ph = cmul(ph, ((h >> q) & 1) ? cconj(gz[1][q].u) : gz[1][q].u);
+            for (int q = 0; q < n; ++q) ph = cmul(ph, ((h >> q) & 1) ? cconj(sh.gz[1][q].u) : sh.gz[1][q].u);
         }
         // wire 4 of a full RX chunk runs as RZ(-pi/2) RY RZ(pi/2) (hea_zyz.hpp, apply_enc): RZ(pi/2) goes into the
         // diagonal before the chunk, RZ(-pi/2) into the one after it; RZ(phi)|b> = e^{-i phi/2 (1 - 2b)}|b>
@@ -209,14 +213,23 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
     } else if (j >= 32 && j < 32 + 2 * n) {
         const int q = (j - 32) >> 1, var = (j - 32) & 1;
         if (cur.kind == 1) {    // (an RX chunk's record keeps this part for the next sub-layer's axes, written by ITS block)
-            double2 e = make_double2(gz[0][q].c, var ? gz[0][q].s : -gz[0][q].s);
+            double2 e = make_double2(sh.gz[0][q].c, var ? sh.gz[0][q].s : -sh.gz[0][q].s);
             *reinterpret_cast<double2*>(out + kRecRy + q * 32 + var * 16) = e;
             if (srec) {     // wire 4: the swap form's variants (c, -s) / (s, c)
-                if (q == 4 && var == 1) e = make_double2(gz[0][q].s, gz[0][q].c);
+                if (q == 4 && var == 1) e = make_double2(sh.gz[0][q].s, sh.gz[0][q].c);
                 *reinterpret_cast<double2*>(srec + (long)l * kRecBytes + kSRecRy + q * 32 + var * 16) = e;
             }
         }
     }
+}
+
+__global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, const double* __restrict__ w,
+                                                      char* __restrict__ rec, char* __restrict__ srec,
+                                                      double* __restrict__ gmap, WorkspaceHeader* hdr) {
+    const int l = blockIdx.x, j = threadIdx.x;
+    if (l == 0 && j == 0) header_init(hdr);
+    __shared__ PrepShared sh;
+    prep_layer_body(runs, n, L, l, j, [&](int s, int k, int q) { return w[(long)s * 3 * n + k * n + q]; }, rec, srec, gmap, sh);
 }
 
 // Deterministic column sums of a row-major [rows, ncols] matrix: a block owns `cols` consecutive columns
@@ -236,7 +249,14 @@ __device__ __forceinline__ double slice_sum(const double* __restrict__ p, long r
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] += q[i * step];
     }
-    for (int i = 0; r < rows; r += nslices, q += step, ++i) a[i] += *q;
+    // the last (up to seven) rows of the slice: all loads issued together, then added where a row exists -- the same
+    // additions as a row-by-row loop, without a memory round trip per row (B = 1024: 256 rows = four per slice, all here)
+    double t[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) t[i] = (r + (long)i * nslices < rows) ? q[i * step] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+        if (r + (long)i * nslices < rows) a[i] += t[i];
     return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
@@ -245,10 +265,15 @@ __device__ __forceinline__ double slice_sum(const double* __restrict__ p, long r
 __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw, long nwaves,
                                                  const double* __restrict__ partial, const double* w /* may alias adam->p */,
                                                  double* __restrict__ grad_w, double* acc /*[kRedThreads]*/,
-                                                 bool poisoned, const double* __restrict__ gmap /* ZYZ-form sums, or nullptr */,
-                                                 const AdamArgs* adam = nullptr, long adam_base = 0) {
-    const int cols = red_cols(kw), nslices = kRedThreads / cols;
+                                                 bool poisoned, const double* gmap /* ZYZ-form sums, or nullptr (the fused path rewrites the block's own entries at its end) */,
+                                                 const AdamArgs* adam = nullptr, long adam_base = 0,
+                                                 int cols_block = 0 /* columns per block if not red_cols(kw) */,
+                                                 double* newp = nullptr /* LDS [cols_block / kw][3][n]: the block's angles after the update */) {
+    // cols_block = 2 red_cols(kw) (fused path, two sub-layers per block): every thread sums TWO of the 64 row slices, so that
+    // each column's additions are exactly those of the one-sub-layer blocks (acc then holds 2 kRedThreads values)
+    const int cols = cols_block ? cols_block : red_cols(kw), nslices = kRedThreads / red_cols(kw);
     const int j = threadIdx.x % cols, slice = threadIdx.x / cols;
+    const int per_thread = cols / red_cols(kw);            // 1 or 2 slices per thread
     const long ncols = (long)blk * kw;
     const long v = (long)bid * cols + j;
     // the thread that will finish gate (s, q) fetches what the finish needs first: gradient-map coefficients and the
@@ -268,6 +293,10 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
         for (int i = 0; i < 3; ++i) { ap[i] = adam->p[base + (long)i * n]; am[i] = adam->m[base + (long)i * n]; av[i] = adam->v[base + (long)i * n]; }
     }
     acc[slice * cols + j] = v < ncols ? slice_sum(partial + v, nwaves, ncols, slice, nslices) : 0.0;
+    if (per_thread == 2) {
+        const int s2 = slice + nslices / 2;
+        acc[s2 * cols + j] = v < ncols ? slice_sum(partial + v, nwaves, ncols, s2, nslices) : 0.0;
+    }
     __syncthreads();
     // slices are combined in two fixed-order stages (8 interleaved groups, then those 8): a quarter of the serial
     // LDS read chain of a single 64-term loop, and still the same order on every run
@@ -309,11 +338,16 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
             gs[2 * n + q] = gc;
             gs[n + q] = gb;
             gs[q] = ga;
+            double pn[3] = {ap[0], ap[1], ap[2]};
             if (upd && !poisoned) {              // this thread alone reads and writes the three angles of gate (s, q)
                 const long base = adam_base + (long)s * 3 * n;
-                adam_update_pre(*adam, base + 2 * n + q, gc, ap[2], am[2], av[2]);
-                adam_update_pre(*adam, base + n + q, gb, ap[1], am[1], av[1]);
-                adam_update_pre(*adam, base + q, ga, ap[0], am[0], av[0]);
+                pn[2] = adam_update_pre(*adam, base + 2 * n + q, gc, ap[2], am[2], av[2]);
+                pn[1] = adam_update_pre(*adam, base + n + q, gb, ap[1], am[1], av[1]);
+                pn[0] = adam_update_pre(*adam, base + q, ga, ap[0], am[0], av[0]);
+            }
+            if (newp) {                          // (only with an update pending: ap holds the current angles)
+                double* np = newp + (long)(s - (int)((long)bid * cols / kw)) * 3 * n;
+                np[q] = pn[0]; np[n + q] = pn[1]; np[2 * n + q] = pn[2];
             }
         }
     }
@@ -632,14 +666,43 @@ struct GradMap {                // where each gradient lives in the flat output
 // frequency-layer gradients from grad_x (16 columns x 64 row slices per block); last block: bias gradient,
 // sse, sum y^2.
 constexpr int kFreqCols = 16, kFreqSlices = kRedThreads / kFreqCols;
+// Records of the NEXT training step written by this one's reduce kernel (qhea_model_train_steps, block-unrolled shapes:
+// every block = one full RX chunk + ld sub-layers).  One reduce block then owns a whole circuit block -- ld x kw columns,
+// its ld sub-layers' angles and Adam state -- and, once it has updated them, three 64-thread groups write the records that
+// depend on nothing else: the block's ld sub-layers' and the FOLLOWING chunk's (or the final record's), whose diagonals
+// take this block's last sub-layer through the ring.  The first chunk's record never changes.  No prep launch then.
+struct FusePrep {
+    int ld;                 // 0: off
+    int L;                  // layer count (records 0 .. L)
+    Runs runs;
+    char* rec; char* srec; double* gmap;
+};
+constexpr int kFuseMaxLd = 2;
+template <bool FUSE>        // (two instantiations: the fused one's LDS and registers do not weigh on the plain one)
 __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         int n, int blk, int kw, long nwaves, const double* __restrict__ partial, const double* w,
         long B, int E, EncDesc enc, const double* __restrict__ grad_x, const double* __restrict__ pred,
         const double* __restrict__ y, double inv_bt, GradMap gm, int nb_w, int nb_x, double* __restrict__ grad,
-        AdamArgs adam, const WorkspaceHeader* __restrict__ hdr, const double* __restrict__ gmap) {
+        AdamArgs adam, const WorkspaceHeader* __restrict__ hdr, const double* gmap, FusePrep fp) {
     __shared__ double acc[kRedThreads];
     __shared__ double acc2[kRedThreads];
     const int bid = blockIdx.x;
+    if constexpr (FUSE) if (bid < nb_w) {           // (block-uniform)
+        __shared__ PrepShared psh[kFuseMaxLd + 1];
+        __shared__ double newp[kFuseMaxLd * 3 * QHEA_MAX_QUBITS];
+        __shared__ double accbig[2 * kRedThreads];
+        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, accbig, hdr->status != 0, gmap, &adam,
+                         gm.off_ans, fp.ld * kw, newp);
+        __syncthreads();
+        const int grp = (int)threadIdx.x >> 6, j = (int)threadIdx.x & 63;
+        const int per = 1 + fp.ld, s0 = bid * fp.ld;
+        const bool act = grp <= fp.ld;
+        const int l = act ? (grp < fp.ld ? bid * per + 1 + grp : (bid + 1) * per) : 0;
+        prep_layer_body(fp.runs, n, fp.L, l, act ? j : -1,
+                        [&](int s, int k, int q) { return newp[(s - s0) * 3 * n + k * n + q]; }, fp.rec, fp.srec, fp.gmap,
+                        psh[act ? grp : 0]);
+        return;
+    }
     // hand-off overrun in the circuit kernel: NaN out, no parameter update.  The word is only USED at the end of each
     // branch: nothing that is loaded before the sums depends on it, so its round trip overlaps theirs.
     const unsigned status = hdr->status;
@@ -1054,10 +1117,20 @@ int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double*
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 
+// the reduce kernel can write the next step's records: ZYZ kernels on a block-unrolled shape whose reduce block (ld x kw
+// columns) divides the block size
+static bool model_fuse_eligible(const ModelInfo& mi, const Layout& L) {
+    const int ld = zyz_fast_ld(mi.sh.runs, mi.n), kw = padded_3n(mi.n);
+    // (kw = 16 = red_cols: a reduce block of ld x 16 columns adds every column exactly as the one-sub-layer blocks do)
+    return (L.ztri || L.zpacked) && ld >= 1 && ld <= kFuseMaxLd && kw == 16 && mi.sh.blk % ld == 0;
+}
+
 static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
                                 const double* y, const double* params, const double* ham_diag, double inv_batch_total,
                                 double* grad, double* pred, void* workspace, size_t workspace_bytes, void* stream,
-                                const AdamArgs& adam) {
+                                const AdamArgs& adam, bool records_ready = false, bool records_for_next = false) {
+    // records_ready / records_for_next (qhea_model_train_steps only): the previous step's reduce kernel has written this
+    // step's layer records / this step's reduce kernel writes the next step's (FusePrep)
     ModelInfo mi;
     int rc = model_info(desc, mi);
     if (rc != QHEA_OK) return rc;
@@ -1078,11 +1151,22 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
     gm.off_ans = mi.off_ans; gm.off_bias = mi.off_bias; gm.off_sse = mi.P;
     for (int s = 0; s < 2; ++s) { gm.off_w[s] = mi.off_w[s]; gm.off_b[s] = mi.off_b[s]; }
     const int kw = padded_3n(mi.n);
-    const int nb_w = (int)((mi.sh.blk * kw + red_cols(kw) - 1) / red_cols(kw));
+    int nb_w = (int)((mi.sh.blk * kw + red_cols(kw) - 1) / red_cols(kw));
     const int nb_x = mi.trainable ? (int)((mi.sh.E + kFreqCols - 1) / kFreqCols) : 0;
+    FusePrep fp{};
     if (M.L.ztri || M.L.zpacked) {
-        rc = launch_prep_zyz(mi.n, mi.sh, params + mi.off_ans, ws, M.L, st);
-        if (rc != QHEA_OK) return rc;
+        if (records_for_next) {
+            if (!model_fuse_eligible(mi, M.L) || !adam.p) return QHEA_EINVAL;
+            fp.ld = zyz_fast_ld(mi.sh.runs, mi.n);
+            fp.L = M.L.zL; fp.runs = mi.sh.runs;
+            fp.rec = ws + M.L.off_rec; fp.srec = M.L.zsplit ? ws + M.L.off_srec : nullptr;
+            fp.gmap = reinterpret_cast<double*>(ws + M.L.off_gmap);
+            nb_w = (int)(mi.sh.blk / fp.ld);                   // one reduce block per circuit block
+        }
+        if (!records_ready) {
+            rc = launch_prep_zyz(mi.n, mi.sh, params + mi.off_ans, ws, M.L, st);
+            if (rc != QHEA_OK) return rc;
+        }
         profile_begin(st);
         rc = launch_zyz_backward(mi.n, mi.sh, batch, M.L, ws, AngleSrc{nullptr, enc}, desc->ham_offset, desc->ham_coeff, ham_diag,
                                  desc->ham_pauli, nullptr, nullptr, y, mi.has_bias ? params + mi.off_bias : nullptr,
@@ -1090,12 +1174,19 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
         profile_end(st);
         if (rc != QHEA_OK) return rc;
         if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
-        hipLaunchKernelGGL(reduce_model_kernel, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
-                           (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
-                           gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws),
-                           reinterpret_cast<const double*>(ws + M.L.off_gmap));
+        if (fp.ld != 0)
+            hipLaunchKernelGGL(reduce_model_kernel<true>, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
+                               (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
+                               gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws),
+                               reinterpret_cast<const double*>(ws + M.L.off_gmap), fp);
+        else
+            hipLaunchKernelGGL(reduce_model_kernel<false>, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
+                               (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
+                               gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws),
+                               reinterpret_cast<const double*>(ws + M.L.off_gmap), fp);
         return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
     }
+    if (records_ready || records_for_next) return QHEA_EINVAL;
     rc = launch_prep_model(mi, batch, params, enc, ws, M.L, st);
     if (rc != QHEA_OK) return rc;
     const dim3 grid((unsigned)(M.L.nwaves / kWaves));
@@ -1116,10 +1207,10 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
     }
     profile_end(st);
     if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
-    hipLaunchKernelGGL(reduce_model_kernel, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
+    hipLaunchKernelGGL(reduce_model_kernel<false>, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
                        (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
                        gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws),
-                       static_cast<const double*>(nullptr));
+                       static_cast<const double*>(nullptr), FusePrep{});
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 
@@ -1158,14 +1249,24 @@ int qhea_model_train_steps(const qhea_model_desc* desc, int64_t n_steps, const i
         if (row_begin[i + 1] <= row_begin[i] || row_begin[i] < 0) return QHEA_EINVAL;
     const bool has_trunk = desc->model == QHEA_MODEL_QUANONET;
     if (has_trunk && !trunk) return QHEA_EINVAL;
+    if (!params || !exp_avg || !exp_avg_sq) return QHEA_EINVAL;
+    // Between two steps of equal batch size (same workspace layout) on a block-unrolled shape the first one's reduce kernel
+    // writes the second one's layer records: nobody else can touch the parameters in between, so the prep launch is dropped.
+    bool ready = false;
     for (int64_t i = 0; i < n_steps; ++i) {
         const int64_t r0 = row_begin[i], nb = row_begin[i + 1] - r0;
-        const int rc = qhea_model_train_step(desc, nb, branch + r0 * desc->branch_in,
-                                             has_trunk ? trunk + r0 * desc->trunk_in : nullptr, y + r0, params, ham_diag,
-                                             inv_batch_total[i], grad + i * grad_stride, nullptr, exp_avg, exp_avg_sq,
-                                             first_step + i, lr, beta1, beta2, eps, weight_decay, workspace,
-                                             workspace_bytes, stream);
+        bool next = false;
+        if (i + 1 < n_steps && row_begin[i + 2] - row_begin[i + 1] == nb)
+            next = model_fuse_eligible(mi, make_model_layout(mi, nb).L);
+        const int64_t step = first_step + i;
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        const AdamArgs adam{params, exp_avg, exp_avg_sq, lr / bc1, 1.0 / sqrt(bc2), beta1, beta2, eps, weight_decay};
+        const int rc = model_loss_grad_impl(desc, nb, branch + r0 * desc->branch_in,
+                                            has_trunk ? trunk + r0 * desc->trunk_in : nullptr, y + r0, params, ham_diag,
+                                            inv_batch_total[i], grad + i * grad_stride, nullptr, workspace, workspace_bytes,
+                                            stream, adam, ready, next);
         if (rc != QHEA_OK) return rc;
+        ready = next;
     }
     return QHEA_OK;
 }

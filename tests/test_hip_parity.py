@@ -580,28 +580,39 @@ def test_float32_module_like_the_reference(dev):
 
 
 @pytest.mark.gpu
-def test_train_steps_from_one_host_call_equal_the_single_steps_bitwise():
-    """qhea_model_train_steps (one epoch's inner loop from one host call) against a loop of qhea_model_train_step:
-    uneven last batch, parameters / Adam state / every step's [grads | sse | sum y^2] row bitwise equal."""
+@pytest.mark.parametrize('nq,net,n_rows,bs', [
+    (4, (3, 2, 2, 1), 230, 64),          # mixed sub-layer counts: the generic walk, a prep launch per step
+    (5, (3, 2, 2, 2), 230, 64),          # block-unrolled shape, LD = 2: steps 2, 3 take their records from the previous reduce
+    (5, (3, 1, 2, 1), 200, 50),          # LD = 1
+    (3, (2, 2, 3, 2), 150, 50),          # n = 3 (pad(3n) = 16 columns per sub-layer)
+    (2, (4, 2, 3, 2), 96, 32),           # n = 2 (8 columns per sub-layer)
+    (5, (2, 2, 2, 2), 3 * 2304 + 100, 2304),   # one-wave ZYZ kernel (batch beyond 3/4 of the SIMDs)
+    (5, (2, 2, 2, 2), 3 * 1024 + 100, 1024),   # two pipelines per workgroup: 256 partial rows, four per row slice
+])
+def test_train_steps_from_one_host_call_equal_the_single_steps_bitwise(nq, net, n_rows, bs):
+    """qhea_model_train_steps (one epoch's inner loop from one host call; on block-unrolled shapes the reduce kernel of a
+    step writes the next step's layer records instead of a prep launch) against a loop of qhea_model_train_step: uneven
+    last batch; parameters, Adam state and every step's [grads | sse | sum y^2] row bitwise equal; then one more single
+    step on both (the records the fused path left behind are not what the next call relies on)."""
     from quanonet_amd.models import QuanONetPT
     from quanonet_amd.solver import DataParallelTrainer
     dev = torch.device('cuda', 0)
     rng = np.random.default_rng(5)
-    n, bs = 230, 64                                             # 3 full batches + one of 38 rows
-    branch = torch.tensor(rng.normal(size=(n, 7)), device=dev)
-    trunk = torch.tensor(rng.uniform(size=(n, 2)), device=dev)
-    y = torch.tensor(rng.normal(size=(n, 1)), device=dev)
-    bounds = [0, 64, 128, 192, 230]
-    gbs = [64, 64, 64, 38]
+    branch = torch.tensor(rng.normal(size=(n_rows, 7)), device=dev)
+    trunk = torch.tensor(rng.uniform(size=(n_rows, 2)), device=dev)
+    y = torch.tensor(rng.normal(size=(n_rows, 1)), device=dev)
+    bounds = list(range(0, n_rows, bs)) + [n_rows]
+    gbs = [bounds[i + 1] - bounds[i] for i in range(len(bounds) - 1)]
+    nst = len(gbs)
 
     def make():
         torch.manual_seed(11)
-        return DataParallelTrainer(QuanONetPT(4, 7, 2, (3, 2, 2, 1), scale_coeff=0.1).double().to(dev), lr=1e-2)
+        return DataParallelTrainer(QuanONetPT(nq, 7, 2, net, scale_coeff=0.1).double().to(dev), lr=1e-2)
     a, b = make(), make()
     assert a.accepts_out
-    rows_a = torch.zeros(4, a.numel + 2, dtype=torch.float64, device=dev)
+    rows_a = torch.zeros(nst, a.numel + 2, dtype=torch.float64, device=dev)
     rows_b = torch.zeros_like(rows_a)
-    for i in range(4):
+    for i in range(nst):
         lo, hi = bounds[i], bounds[i + 1]
         a.train_step(branch[lo:hi], trunk[lo:hi], y[lo:hi], global_batch=gbs[i], out=rows_a[i])
     b.train_steps([branch, trunk], y, bounds, gbs, rows_b)
@@ -609,5 +620,9 @@ def test_train_steps_from_one_host_call_equal_the_single_steps_bitwise():
     assert torch.equal(rows_a, rows_b)
     assert torch.equal(a.pflat, b.pflat)
     assert torch.equal(a.optimizer.exp_avg, b.optimizer.exp_avg) and torch.equal(a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq)
-    assert a.optimizer.t == b.optimizer.t == 4
+    assert a.optimizer.t == b.optimizer.t == nst
     assert float(rows_a[:, a.numel].min()) > 0.0                # every step reported its sse
+    fa = a.train_step(branch[:bs], trunk[:bs], y[:bs]).clone()
+    fb = b.train_step(branch[:bs], trunk[:bs], y[:bs]).clone()
+    assert torch.equal(fa, fb) and torch.equal(a.pflat, b.pflat)
+    a.check_status(); b.check_status()
