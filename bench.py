@@ -137,6 +137,21 @@ def main():
         return trainer.train_step(branch[s:s + batch], trunk[s:s + batch], y[s:s + batch],
                                   global_batch=batch * world)
 
+    # One device: the steps are issued as the product's epoch loop issues them (PTSolver.train -> qhea_model_train_steps):
+    # runs of consecutive steps from one host call, inside which a step's reduce kernel writes the next step's layer
+    # records instead of a prep launch.  Same batches in the same order as the per-step loop (step i: batch i mod 8).
+    epoch_call = world == 1 and trainer.accepts_out and not os.environ.get('QHEA_BENCH_PER_STEP')
+    rows = torch.zeros(n_batches, trainer.numel + 2, dtype=torch.float64, device=dev) if epoch_call else None
+    bounds = [j * batch for j in range(n_batches + 1)]
+
+    def run_steps(first, k):
+        done = 0
+        while done < k:
+            start = (first + done) % n_batches
+            m = min(n_batches - start, k - done)
+            trainer.train_steps([branch, trunk], y, bounds[start:start + m + 1], [batch * world] * m, rows[start:start + m])
+            done += m
+
     def fence():
         if dist is not None:
             dist.barrier()
@@ -153,8 +168,11 @@ def main():
         """EXACTLY k calls bracketed by barrier + synchronize on both sides; max over ranks."""
         fence()
         t0 = time.perf_counter()
-        for i in range(k):
-            fn(first + i)
+        if fn is step and epoch_call:
+            run_steps(first, k)
+        else:
+            for i in range(k):
+                fn(first + i)
         fence()
         return rank_max(time.perf_counter() - t0)
 
@@ -166,8 +184,11 @@ def main():
         wins = [w0] + [timed_window(fn, k, (j + 1) * k) for j in range(n_win - 1)]
         return float(np.median(wins)), wins
 
-    for i in range(args.warmup):
-        step(i)
+    if epoch_call:
+        run_steps(0, args.warmup)
+    else:
+        for i in range(args.warmup):
+            step(i)
     elapsed, windows = measure(step, args.steps)
     samples_per_s = batch * world * args.steps / elapsed
     trainer.check_status()
@@ -230,6 +251,9 @@ def main():
                        "ms_per_step_first_window": 1e3 * windows[0] / args.steps,
                        "ms_per_step_min": 1e3 * min(windows) / args.steps,
                        "ms_per_step_max": 1e3 * max(windows) / args.steps,
+                       "issue": ("runs of up to 8 consecutive steps per host call (qhea_model_train_steps, the epoch loop of "
+                                 "PTSolver.train: a step's reduce kernel writes the next step's layer records)"
+                                 if epoch_call else "one host call per step (prep, circuit, reduce launches each)"),
                        "note": "value = median over windows of EXACTLY `steps` training steps each, every window "
                                "bracketed by barrier + device synchronize, max over ranks per window"},
             "circuit_evals_per_s": evals_per_s,
