@@ -128,7 +128,7 @@ def main():
     model = QuanONetPT(N_QUBITS, B_IN, T_IN, NET, scale_coeff=0.1, if_trainable_freq=True).to(dev)
     trainer = DataParallelTrainer(model, lr=1e-4, world_size=world, dist=dist)
 
-    n_batches = int(os.environ.get("QHEA_BENCH_NB", "8"))      # device-resident synthetic set, cycled
+    n_batches = 8                                             # device-resident synthetic set, cycled
     branch, trunk, y = synth(rank, n_batches * batch)
     branch = torch.tensor(branch, device=dev); trunk = torch.tensor(trunk, device=dev); y = torch.tensor(y, device=dev)
 
