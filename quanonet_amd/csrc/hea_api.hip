@@ -1121,8 +1121,10 @@ int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double*
 // columns) divides the block size
 static bool model_fuse_eligible(const ModelInfo& mi, const Layout& L) {
     const int ld = zyz_fast_ld(mi.sh.runs, mi.n), kw = padded_3n(mi.n);
-    // (kw = 16 = red_cols: a reduce block of ld x 16 columns adds every column exactly as the one-sub-layer blocks do)
-    return (L.ztri || L.zpacked) && ld >= 1 && ld <= kFuseMaxLd && kw == 16 && mi.sh.blk % ld == 0;
+    // (a reduce block of ld x kw = 16 or 32 columns adds every column exactly as the plain 16-column blocks do; n = 2 with
+    //  one sub-layer per block would need two circuit blocks per reduce block: not built)
+    const int cols = ld * kw;
+    return (L.ztri || L.zpacked) && ld >= 1 && ld <= kFuseMaxLd && (cols == 16 || cols == 32) && mi.sh.blk % ld == 0;
 }
 
 static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
