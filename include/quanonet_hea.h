@@ -215,6 +215,17 @@ int qhea_model_forward(const qhea_model_desc* desc, int64_t batch,
                        double* pred /*DEVICE [B]*/, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * qhea_model_forward over `n_chunks` consecutive row ranges [row_begin[i], row_begin[i+1]) of the same arrays with the
+ * SAME parameters -- the chunk loop of PTSolver.evaluate / infer.predict (solvers/solver_pt.py:299-310, infer.py:274-289) in
+ * one host call.  The layer records depend on the parameters alone, so one preparation launch serves all chunks of
+ * equal size; results are bitwise those of the single calls.  The workspace must fit the largest chunk.
+ */
+int qhea_model_forward_chunks(const qhea_model_desc* desc, int64_t n_chunks, const int64_t* row_begin /*HOST [n_chunks+1]*/,
+                              const double* branch /*DEVICE*/, const double* trunk /*DEVICE or NULL*/,
+                              const double* params /*DEVICE flat*/, const double* ham_diag, double* pred /*DEVICE [rows]*/,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * One fused loss + gradient evaluation:
  *   pred_b = model(...);  loss contribution = (pred_b - y_b)^2 * inv_batch_total;
  *   grad[0..P) = d/dparams sum_b (pred_b - y_b)^2 * inv_batch_total;  grad[P] = sum_b (pred_b-y_b)^2;

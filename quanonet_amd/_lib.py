@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('QHEA_LIB') or os.path.join(_HERE, 'libquanonet_hea.so
 
 EXPORTS = ['qhea_version', 'qhea_strerror', 'qhea_device_count', 'qhea_workspace_bytes',
            'qhea_forward', 'qhea_backward', 'qhea_model_param_count', 'qhea_model_workspace_bytes',
-           'qhea_model_forward', 'qhea_model_loss_grad', 'qhea_model_train_step', 'qhea_model_train_steps',
+           'qhea_model_forward', 'qhea_model_forward_chunks', 'qhea_model_loss_grad', 'qhea_model_train_step', 'qhea_model_train_steps',
            'qhea_profile_next_circuit_kernel',
            'qhea_adam_step', 'qhea_set_backward_variant', 'qhea_check_status',
            'qhea_dp_buffer_bytes', 'qhea_dp_alloc', 'qhea_dp_free', 'qhea_dp_export', 'qhea_dp_import', 'qhea_dp_close',
@@ -93,6 +93,8 @@ def load():
     mdp = ctypes.POINTER(ModelDesc)
     i64p = ctypes.POINTER(ctypes.c_int64)
     f64p = ctypes.POINTER(ctypes.c_double)
+    lib.qhea_model_forward_chunks.restype = ctypes.c_int
+    lib.qhea_model_forward_chunks.argtypes = [mdp, ctypes.c_int64, i64p, dp, dp, dp, dp, dp, vp, ctypes.c_size_t, vp]
     lib.qhea_model_train_steps.restype = ctypes.c_int
     lib.qhea_model_train_steps.argtypes = [mdp, ctypes.c_int64, i64p, dp, dp, dp, dp, dp, f64p, dp, ctypes.c_int64, dp, dp,
                                            ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
@@ -291,6 +293,31 @@ def model_forward(desc, branch, trunk, params, ham_diag=None, out=None):
         rc = lib.qhea_model_forward(ctypes.byref(desc), B, _ptr(branch), _ptr(trunk), _ptr(params), _ptr(ham_diag),
                                     _ptr(pred), _ptr(ws), ws.numel(), _stream(branch.device))
     _check(rc, 'qhea_model_forward')
+    return pred
+
+
+def model_forward_chunks(desc, branch, trunk, params, chunk, ham_diag=None, out=None):
+    """model_forward over all rows in chunks of `chunk` rows from ONE host call: one record preparation for all equal-sized
+    chunks (qhea_model_forward_chunks); bitwise the chunk-by-chunk calls."""
+    lib = load()
+    N = branch.shape[0]
+    _dev_f64(branch, 'branch', (N, desc.branch_in))
+    if desc.model == MODEL_QUANONET:
+        _dev_f64(trunk, 'trunk', (N, desc.trunk_in))
+    _dev_f64(params, 'params')
+    _dev_f64(ham_diag, 'ham_diag', (1 << desc.n_qubits,))
+    pred = out if out is not None else torch.empty(N, dtype=torch.float64, device=branch.device)
+    if N == 0:
+        return pred
+    chunk = max(1, int(chunk))
+    bounds = list(range(0, N, chunk)) + [N]
+    nbytes = int(lib.qhea_model_workspace_bytes(ctypes.byref(desc), min(chunk, N)))
+    ws = _workspace(branch.device, nbytes)
+    rb = (ctypes.c_int64 * len(bounds))(*bounds)
+    with torch.cuda.device(branch.device):
+        rc = lib.qhea_model_forward_chunks(ctypes.byref(desc), len(bounds) - 1, rb, _ptr(branch), _ptr(trunk), _ptr(params),
+                                           _ptr(ham_diag), _ptr(pred), _ptr(ws), ws.numel(), _stream(branch.device))
+    _check(rc, 'qhea_model_forward_chunks')
     return pred
 
 

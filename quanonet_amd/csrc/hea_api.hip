@@ -1074,9 +1074,10 @@ size_t qhea_model_workspace_bytes(const qhea_model_desc* desc, int64_t batch) {
     return make_model_layout(mi, batch).total;
 }
 
-int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
-                       const double* params, const double* ham_diag, double* pred, void* workspace,
-                       size_t workspace_bytes, void* stream) {
+// records_ready (qhea_model_forward_chunks only): an earlier chunk of the same call has left this layout's layer records
+static int model_forward_impl(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
+                              const double* params, const double* ham_diag, double* pred, void* workspace,
+                              size_t workspace_bytes, void* stream, bool records_ready) {
     ModelInfo mi;
     int rc = model_info(desc, mi);
     if (rc != QHEA_OK) return rc;
@@ -1089,8 +1090,10 @@ int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double*
     char* ws = static_cast<char*>(workspace);
     const EncDesc enc = make_enc(desc, mi, branch, trunk, params);
     if (M.L.zfwd) {
-        rc = launch_prep_zyz(mi.n, mi.sh, params + mi.off_ans, ws, M.L, st);
-        if (rc != QHEA_OK) return rc;
+        if (!records_ready) {
+            rc = launch_prep_zyz(mi.n, mi.sh, params + mi.off_ans, ws, M.L, st);
+            if (rc != QHEA_OK) return rc;
+        }
         profile_begin(st);
         rc = launch_zyz_forward(mi.n, mi.sh, batch, M.L, ws, AngleSrc{nullptr, enc}, desc->ham_offset, desc->ham_coeff, ham_diag,
                                 desc->ham_pauli, pred, nullptr, mi.has_bias ? params + mi.off_bias : nullptr, st);
@@ -1214,6 +1217,41 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
                        gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws),
                        static_cast<const double*>(nullptr), FusePrep{});
     return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+}
+
+int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
+                       const double* params, const double* ham_diag, double* pred, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    return model_forward_impl(desc, batch, branch, trunk, params, ham_diag, pred, workspace, workspace_bytes, stream, false);
+}
+
+int qhea_model_forward_chunks(const qhea_model_desc* desc, int64_t n_chunks, const int64_t* row_begin,
+                              const double* branch, const double* trunk, const double* params, const double* ham_diag,
+                              double* pred, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!desc || n_chunks < 0 || !row_begin || !branch || !params || !pred) return QHEA_EINVAL;
+    ModelInfo mi;
+    const int rc0 = model_info(desc, mi);
+    if (rc0 != QHEA_OK) return rc0;
+    const bool has_trunk = desc->model == QHEA_MODEL_QUANONET;
+    if (has_trunk && !trunk) return QHEA_EINVAL;
+    for (int64_t i = 0; i < n_chunks; ++i)
+        if (row_begin[i + 1] <= row_begin[i] || row_begin[i] < 0) return QHEA_EINVAL;
+    // the layer records depend on the parameters alone: one prep launch serves every chunk whose workspace layout keeps
+    // them where the last prep put them (chunks of equal size; a shorter last chunk gets its own)
+    Layout last{};
+    bool have = false;
+    for (int64_t i = 0; i < n_chunks; ++i) {
+        const int64_t r0 = row_begin[i], nb = row_begin[i + 1] - r0;
+        const Layout L = make_model_layout(mi, nb).L;
+        const bool ready = have && L.zfwd && last.zfwd && L.off_rec == last.off_rec && L.off_srec == last.off_srec &&
+                           L.off_gmap == last.off_gmap && L.zsplit == last.zsplit && L.zL == last.zL;
+        const int rc = model_forward_impl(desc, nb, branch + r0 * desc->branch_in,
+                                          has_trunk ? trunk + r0 * desc->trunk_in : nullptr, params, ham_diag, pred + r0,
+                                          workspace, workspace_bytes, stream, ready);
+        if (rc != QHEA_OK) return rc;
+        if (!ready) { last = L; have = true; }
+    }
+    return QHEA_OK;
 }
 
 int qhea_model_loss_grad(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,

@@ -566,15 +566,17 @@ class PTSolver:
         self.model.eval()
         tr = self.trainer
         with torch.no_grad():
+            if tr.desc is not None and n > 0:
+                # all chunks from one host call: the layer records are prepared once for the whole set (the parameters
+                # do not change during an evaluation)
+                from . import _lib
+                ins = [t.contiguous() for t in inputs]
+                o = _lib.model_forward_chunks(tr.desc, ins[0], ins[1] if len(ins) > 1 else None, tr.pflat, bs,
+                                              ham_diag=tr._ham_diag())
+                return o.unsqueeze(-1)
             for s in range(0, n, bs):
                 chunk = [t[s:s + bs] for t in inputs]
-                if tr.desc is not None:
-                    from . import _lib
-                    o = _lib.model_forward(tr.desc, chunk[0], chunk[1] if len(chunk) > 1 else None, tr.pflat,
-                                           ham_diag=tr._ham_diag())
-                    outs.append(o.unsqueeze(-1))
-                else:
-                    outs.append(self.model(*chunk))
+                outs.append(self.model(*chunk))
         if not outs:                                            # an empty shard (fewer test rows than ranks)
             return torch.empty((0, 1), dtype=torch.float64, device=inputs[0].device)
         return torch.cat(outs, dim=0)

@@ -626,3 +626,27 @@ def test_train_steps_from_one_host_call_equal_the_single_steps_bitwise(nq, net, 
     fb = b.train_step(branch[:bs], trunk[:bs], y[:bs]).clone()
     assert torch.equal(fa, fb) and torch.equal(a.pflat, b.pflat)
     a.check_status(); b.check_status()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nq,net', [(5, (3, 2, 2, 2)), (4, (3, 2, 2, 1)), (8, (2, 2, 2, 2))])
+def test_forward_chunks_from_one_host_call_equal_the_single_calls_bitwise(nq, net):
+    """qhea_model_forward_chunks (one record preparation for all equal-sized chunks) against chunk-by-chunk
+    qhea_model_forward, with a shorter last chunk; and PTSolver-style predict on top of it."""
+    from quanonet_amd.models import QuanONetPT
+    from quanonet_amd.solver import DataParallelTrainer
+    from quanonet_amd import _lib
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(9)
+    n_rows, chunk = 700, 256
+    branch = torch.tensor(rng.normal(size=(n_rows, 7)), device=dev)
+    trunk = torch.tensor(rng.uniform(size=(n_rows, 2)), device=dev)
+    torch.manual_seed(3)
+    tr = DataParallelTrainer(QuanONetPT(nq, 7, 2, net, scale_coeff=0.1).double().to(dev))
+    one = torch.cat([_lib.model_forward(tr.desc, branch[s:s + chunk], trunk[s:s + chunk], tr.pflat)
+                     for s in range(0, n_rows, chunk)])
+    many = _lib.model_forward_chunks(tr.desc, branch, trunk, tr.pflat, chunk)
+    torch.cuda.synchronize()
+    assert torch.equal(one, many)
+    whole = _lib.model_forward(tr.desc, branch, trunk, tr.pflat)
+    assert float((whole - many).abs().max()) < 1e-12
