@@ -274,6 +274,10 @@ def main():
                        "note": "value = median over windows of EXACTLY `steps` training steps each, every window "
                                "bracketed by barrier + device synchronize, max over ranks per window"},
             "circuit_evals_per_s": evals_per_s,
+            "circuit_evals_issue": ("one host call per forward launch (record preparation every call)"
+                                    if os.environ.get('QHEA_BENCH_PER_STEP') else
+                                    "the resident set in chunks of one batch per host call (qhea_model_forward_chunks, what "
+                                    "PTSolver.predict runs: one record preparation per call, one forward launch per batch)"),
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
