@@ -57,9 +57,22 @@ def threads():
     return lib().qhea_oracle_threads()
 
 
+def _fit_columns(x, block_configs):
+    """The reference applies an encoding gate only while its column cursor is inside x (core/quantum_circuits_tq.py:83):
+    missing columns are skipped gates (= zero angles, RX(0) = 1), surplus columns are never read.  The C routine takes
+    exactly E columns."""
+    E = sum(c[0] for c in block_configs)
+    x = np.asarray(x, dtype=np.float64)
+    if x.shape[1] > E:
+        x = x[:, :E]
+    elif x.shape[1] < E:
+        x = np.concatenate([x, np.zeros((x.shape[0], E - x.shape[1]))], axis=1)
+    return np.ascontiguousarray(x)
+
+
 def hea_forward(num_qubits, block_configs, x, w, offset=0.0, coeff=1.0, ham_diag=None,
                 return_state=False, ham_pauli='Z'):
-    x = np.ascontiguousarray(x, dtype=np.float64)
+    x = _fit_columns(x, block_configs)
     w = np.ascontiguousarray(w, dtype=np.float64)
     diag = None if ham_diag is None else np.ascontiguousarray(ham_diag, dtype=np.float64)
     B = x.shape[0]
@@ -74,7 +87,8 @@ def hea_forward(num_qubits, block_configs, x, w, offset=0.0, coeff=1.0, ham_diag
 
 
 def hea_backward(num_qubits, block_configs, x, w, g, offset=0.0, coeff=1.0, ham_diag=None, ham_pauli='Z'):
-    x = np.ascontiguousarray(x, dtype=np.float64)
+    width = np.asarray(x).shape[1]
+    x = _fit_columns(x, block_configs)
     w = np.ascontiguousarray(w, dtype=np.float64)
     g = np.ascontiguousarray(g, dtype=np.float64).reshape(-1)
     diag = None if ham_diag is None else np.ascontiguousarray(ham_diag, dtype=np.float64)
@@ -88,4 +102,8 @@ def hea_backward(num_qubits, block_configs, x, w, g, offset=0.0, coeff=1.0, ham_
                                     _p(out), _p(gx), _p(gw))
     if rc:
         raise ValueError(f"qhea_oracle_backward failed ({rc})")
+    if width != x.shape[1]:                      # gradient in the caller's own width (surplus columns: zero)
+        full = np.zeros((B, width))
+        full[:, :min(width, x.shape[1])] = gx[:, :min(width, x.shape[1])]
+        gx = full
     return out, gx, gw

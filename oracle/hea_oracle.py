@@ -155,7 +155,8 @@ def hea_state(num_qubits, block_configs, x, w):
     blk = 0
     for n_enc, ld in block_configs:
         for j in range(n_enc):
-            _rx(psi, n, j % n, x[:, col])
+            if col < x.shape[1]:                          # quantum_circuits_tq.py:83: no column, no gate
+                _rx(psi, n, j % n, x[:, col])
             col += 1
         for _ in range(ld):
             for i in range(n):
@@ -236,7 +237,8 @@ def hea_backward(num_qubits, block_configs, x, w, g, offset=0.0, coeff=1.0, ham_
     blk = 0
     for n_enc, ld in block_configs:
         for j in range(n_enc):
-            ops.append(('rx', j % n, col))
+            if col < E:                                   # quantum_circuits_tq.py:83 (grad_x has x's own width)
+                ops.append(('rx', j % n, col))
             col += 1
         for _ in range(ld):
             for i in range(n):

@@ -107,8 +107,17 @@ class HEACircuitHIP(nn.Module):
         return self._shape.E
 
     def forward(self, x):
-        if x.dim() != 2 or x.shape[1] != self._shape.E:
+        if x.dim() != 2:
             raise ValueError(f"expected x of shape (batch, {self._shape.E}), got {tuple(x.shape)}")
+        # The reference walks a column cursor over x and applies an encoding gate only while the cursor is inside x
+        # (`if param_col < x.shape[1]`, core/quantum_circuits_tq.py:83): missing columns are skipped gates, surplus
+        # columns are never read.  RX(0) is the identity, so a skipped gate is a zero angle; the C ABI itself takes
+        # exactly E columns (include/quanonet_hea.h: qhea_forward).
+        E = self._shape.E
+        if x.shape[1] > E:
+            x = x[:, :E]
+        elif x.shape[1] < E:
+            x = torch.nn.functional.pad(x, (0, E - x.shape[1]))
         diag = self.ham_diag if self.use_full_ham else None
         out = _HEAFunction.apply(x, self.ansatz_weights, self._shape, self.ham_offset, self.ham_coeff, diag,
                                  self.ham_pauli)

@@ -650,3 +650,27 @@ def test_forward_chunks_from_one_host_call_equal_the_single_calls_bitwise(nq, ne
     assert torch.equal(one, many)
     whole = _lib.model_forward(tr.desc, branch, trunk, tr.pflat)
     assert float((whole - many).abs().max()) < 1e-12
+
+
+def test_module_mirrors_the_reference_column_guard(dev):
+    """core/quantum_circuits_tq.py:83: an x narrower than E skips the missing encoding gates, a wider x is not read beyond
+    E; HEACircuitHIP.forward does the same (zero angles / slice), forward and both gradients against the oracle."""
+    from quanonet_amd.circuit import HEACircuitHIP
+    n, cfgs = 4, O.block_configs_quanonet(4, (2, 2, 1, 1))
+    E, blk = O.circuit_sizes(n, cfgs)
+    off, co = O.ham_params(n)
+    torch.manual_seed(2)
+    layer = HEACircuitHIP(n, cfgs, ham_offset=off, ham_coeff_per_qubit=co).to(dev)
+    w = layer.ansatz_weights.detach().cpu().numpy()
+    rng = np.random.default_rng(3)
+    g = rng.normal(size=9)
+    for width in (E - 3, E + 2):
+        x = rng.uniform(-np.pi, np.pi, (9, width))
+        xt = _t(x, dev).requires_grad_(True)
+        layer.zero_grad()
+        out = layer(xt)
+        (out[:, 0] * _t(g, dev)).sum().backward()
+        ro, rgx, rgw = O.hea_backward(n, cfgs, x, w, g, off, co)
+        np.testing.assert_allclose(out[:, 0].detach().cpu().numpy(), ro, rtol=0, atol=TOL)
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), rgx, rtol=0, atol=TOL)
+        np.testing.assert_allclose(layer.ansatz_weights.grad.cpu().numpy(), rgw, rtol=0, atol=TOL)

@@ -307,3 +307,31 @@ def test_k9_readme_demo_figures():
     assert abs(np.mean(np.abs(diff)) - ka['seed0']['mae']) < 5e-5
     for k, v in (('rel_l2', rel), ('mse', np.mean(diff ** 2)), ('mae', np.mean(np.abs(diff)))):
         assert abs(v - ka['readme'][k]) < 0.1 * ka['readme'][k], k        # within 10 % of the README's own sample
+
+
+def test_encoding_column_guard_like_the_reference():
+    """core/quantum_circuits_tq.py:83 (`if param_col < x.shape[1]`): an x narrower than E skips the missing encoding gates
+    (equal to zero angles: RX(0) = 1), a wider x is never read beyond E.  numpy and C restatements; the product module
+    mirrors it in HEACircuitHIP.forward (tests/test_hip_parity.py)."""
+    from oracle import c_oracle as C
+    n, cfgs = 3, O.block_configs_quanonet(3, (2, 1, 1, 2))
+    E, blk = O.circuit_sizes(n, cfgs)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-np.pi, np.pi, (4, E)); w = rng.uniform(-np.pi, np.pi, (blk, 3, n)); g = rng.normal(size=4)
+    narrow = x[:, :E - 4]
+    padded = np.concatenate([narrow, np.zeros((4, 4))], axis=1)
+    wide = np.concatenate([x, rng.normal(size=(4, 3))], axis=1)
+    for eng in (O, C):
+        o_n, gx_n, gw_n = eng.hea_backward(n, cfgs, narrow, w, g, 0.0, 5.0 / n)
+        o_p, gx_p, gw_p = eng.hea_backward(n, cfgs, padded, w, g, 0.0, 5.0 / n)
+        assert gx_n.shape == narrow.shape
+        np.testing.assert_allclose(o_n, o_p, atol=1e-14); np.testing.assert_allclose(gw_n, gw_p, atol=1e-13)
+        np.testing.assert_allclose(gx_n, gx_p[:, :E - 4], atol=1e-14)
+        np.testing.assert_allclose(eng.hea_forward(n, cfgs, narrow, w, 0.0, 5.0 / n), o_p, atol=1e-14)
+        o_w, gx_w, gw_w = eng.hea_backward(n, cfgs, wide, w, g, 0.0, 5.0 / n)
+        o_x, gx_x, gw_x = eng.hea_backward(n, cfgs, x, w, g, 0.0, 5.0 / n)
+        assert gx_w.shape == wide.shape and not gx_w[:, E:].any()
+        np.testing.assert_allclose(o_w, o_x, atol=1e-14); np.testing.assert_allclose(gx_w[:, :E], gx_x, atol=1e-14)
+        np.testing.assert_allclose(gw_w, gw_x, atol=1e-13)
+    # narrow really skips gates: it differs from the full-width result
+    assert np.abs(O.hea_forward(n, cfgs, narrow, w, 0.0, 5.0 / n) - O.hea_forward(n, cfgs, x, w, 0.0, 5.0 / n)).max() > 1e-3
