@@ -177,6 +177,14 @@ def _ptr(t):
 _workspaces = {}
 
 
+def _model_ws(desc, rows, device):
+    """Workspace for a model-level call on `rows` rows; the size query runs with `device` current (the layout follows that
+    device's SIMD count)."""
+    with torch.cuda.device(device):
+        nbytes = int(load().qhea_model_workspace_bytes(ctypes.byref(desc), int(rows)))
+    return _workspace(device, nbytes)
+
+
 def _workspace(device, nbytes):
     """Grow-only per-device scratch tensor (caller-owned from the C ABI's point of view)."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
@@ -224,7 +232,8 @@ def hea_forward(shape, x, w, ham_offset, ham_coeff, ham_diag=None, return_state=
     _dev_f64(ham_diag, 'ham_diag', (1 << shape.n,))
     out = torch.empty(B, dtype=torch.float64, device=x.device)
     state = torch.empty((B, 1 << shape.n, 2), dtype=torch.float64, device=x.device) if return_state else None
-    nbytes = shape.workspace_bytes(B)
+    with torch.cuda.device(x.device):                 # the layout follows the current device's SIMD count
+        nbytes = shape.workspace_bytes(B)
     ws = _workspace(x.device, nbytes)
     with torch.cuda.device(x.device):
         rc = lib.qhea_forward(shape.n, shape.nb, shape._enc, shape._ld, B, _ptr(x), _ptr(w),
@@ -247,7 +256,8 @@ def hea_backward(shape, x, w, g, ham_offset, ham_coeff, ham_diag=None, state=Non
     grad_x = torch.empty_like(x)
     grad_w = torch.empty_like(w)
     out = torch.empty(B, dtype=torch.float64, device=x.device) if want_out else None
-    nbytes = shape.workspace_bytes(B)
+    with torch.cuda.device(x.device):                 # the layout follows the current device's SIMD count
+        nbytes = shape.workspace_bytes(B)
     ws = _workspace(x.device, nbytes)
     with torch.cuda.device(x.device):
         rc = lib.qhea_backward(shape.n, shape.nb, shape._enc, shape._ld, B, _ptr(x), _ptr(w),
@@ -287,8 +297,7 @@ def model_forward(desc, branch, trunk, params, ham_diag=None, out=None):
     _dev_f64(params, 'params')
     _dev_f64(ham_diag, 'ham_diag', (1 << desc.n_qubits,))
     pred = out if out is not None else torch.empty(B, dtype=torch.float64, device=branch.device)
-    nbytes = int(lib.qhea_model_workspace_bytes(ctypes.byref(desc), B))
-    ws = _workspace(branch.device, nbytes)
+    ws = _model_ws(desc, B, branch.device)
     with torch.cuda.device(branch.device):
         rc = lib.qhea_model_forward(ctypes.byref(desc), B, _ptr(branch), _ptr(trunk), _ptr(params), _ptr(ham_diag),
                                     _ptr(pred), _ptr(ws), ws.numel(), _stream(branch.device))
@@ -311,8 +320,7 @@ def model_forward_chunks(desc, branch, trunk, params, chunk, ham_diag=None, out=
         return pred
     chunk = max(1, int(chunk))
     bounds = list(range(0, N, chunk)) + [N]
-    nbytes = int(lib.qhea_model_workspace_bytes(ctypes.byref(desc), min(chunk, N)))
-    ws = _workspace(branch.device, nbytes)
+    ws = _model_ws(desc, min(chunk, N), branch.device)
     rb = (ctypes.c_int64 * len(bounds))(*bounds)
     with torch.cuda.device(branch.device):
         rc = lib.qhea_model_forward_chunks(ctypes.byref(desc), len(bounds) - 1, rb, _ptr(branch), _ptr(trunk), _ptr(params),
@@ -335,8 +343,7 @@ def model_loss_grad(desc, branch, trunk, y, params, inv_batch_total, grad, ham_d
     _dev_f64(grad, 'grad')
     _dev_f64(ham_diag, 'ham_diag', (1 << desc.n_qubits,))
     _dev_f64(pred, 'pred', (B,))
-    nbytes = int(lib.qhea_model_workspace_bytes(ctypes.byref(desc), B))
-    ws = _workspace(branch.device, nbytes)
+    ws = _model_ws(desc, B, branch.device)
     with torch.cuda.device(branch.device):
         rc = lib.qhea_model_loss_grad(ctypes.byref(desc), B, _ptr(branch), _ptr(trunk), _ptr(y), _ptr(params),
                                       _ptr(ham_diag), float(inv_batch_total), _ptr(grad), _ptr(pred),
@@ -362,8 +369,7 @@ def model_train_step(desc, branch, trunk, y, params, inv_batch_total, grad, exp_
         raise QheaError("model_train_step: flat vectors have inconsistent lengths")
     _dev_f64(ham_diag, 'ham_diag', (1 << desc.n_qubits,))
     _dev_f64(pred, 'pred', (B,))
-    nbytes = int(lib.qhea_model_workspace_bytes(ctypes.byref(desc), B))
-    ws = _workspace(branch.device, nbytes)
+    ws = _model_ws(desc, B, branch.device)
     with torch.cuda.device(branch.device):
         rc = lib.qhea_model_train_step(ctypes.byref(desc), B, _ptr(branch), _ptr(trunk), _ptr(y), _ptr(params),
                                        _ptr(ham_diag), float(inv_batch_total), _ptr(grad), _ptr(pred),
@@ -398,8 +404,7 @@ def model_train_steps(desc, bounds, global_batches, branch, trunk, y, params, ro
         raise QheaError("model_train_steps: flat vectors have inconsistent lengths")
     _dev_f64(ham_diag, 'ham_diag', (1 << desc.n_qubits,))
     biggest = max(bounds[i + 1] - bounds[i] for i in range(n_steps))
-    nbytes = int(lib.qhea_model_workspace_bytes(ctypes.byref(desc), biggest))
-    ws = _workspace(branch.device, nbytes)
+    ws = _model_ws(desc, biggest, branch.device)
     rb = (ctypes.c_int64 * (n_steps + 1))(*[int(b) for b in bounds])
     ib = (ctypes.c_double * n_steps)(*[1.0 / float(g) for g in global_batches])
     with torch.cuda.device(branch.device):

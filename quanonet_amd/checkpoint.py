@@ -12,6 +12,7 @@ Checkpoint / weight-format interop.
   same grammar as the reference's ``infer.py:37-86`` / ``utils/logger.py:55-118``.
 """
 import os
+import re
 import numpy as np
 
 _DTYPES = {
@@ -173,18 +174,25 @@ def pt_to_ms_state(state, model_type='QuanONet'):
     return out
 
 
+_NUMBER = re.compile(r'-?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?')
+
+
 def _signed_list(text):
-    """'-5-5' / '0.5--1' -> numbers: the writer joins str(v) with '-' (utils/logger.py:98-103), so an empty piece
-    between two dashes announces a negative value."""
-    vals, neg = [], False
-    for piece in text.split('-'):
-        if piece == '':
-            neg = True
-            continue
-        v = float(piece)
-        vals.append(-v if neg else v)
-        neg = False
-    return vals
+    """'-5-5' / '0.5--1' / '1e-05-2' -> numbers, or None when the text is not such a list.  The writer joins str(v)
+    with '-' (utils/logger.py:98-103): a number may carry its own sign and an exponent ('1e-05'), so the text is read
+    number by number with one separating dash between two of them, not split on dashes."""
+    vals, pos = [], 0
+    while pos < len(text):
+        if vals:
+            if text[pos] != '-':
+                return None
+            pos += 1
+        m = _NUMBER.match(text, pos)
+        if m is None:
+            return None
+        vals.append(float(m.group()))
+        pos = m.end()
+    return vals or None
 
 
 _BACKEND_TOKENS = {'TQ': 'torchquantum', 'Qiskit': 'qiskit', 'PL': 'pennylane', 'HIP': 'hip',
@@ -204,30 +212,36 @@ def parse_experiment_dir(path):
         path = os.path.dirname(os.path.abspath(path))
     cfg = {}
     fields = os.path.basename(path).split('_')
-    for pos, tok in enumerate(fields):
+    # everything left of the model token is the operator's name, which may itself contain '_' and look like a
+    # hyper-parameter ('Q2', 'S1'): the recognisers below only see the fields to the right of the model
+    start = next((i for i, t in enumerate(fields) if t in ('QuanONet', 'HEAQNN', 'DeepONet', 'FNN', 'FNO')), None)
+    if start is None:
+        return cfg
+    cfg['model_type'] = fields[start]
+    if start > 0:
+        cfg['operator'] = '_'.join(fields[:start])
+    for tok in fields[start + 1:]:
         head3, head1 = tok[:3], tok[:1]
-        if tok in ('QuanONet', 'HEAQNN', 'DeepONet', 'FNN', 'FNO') and 'model_type' not in cfg:
-            cfg['model_type'] = tok
-            if pos > 0:
-                cfg['operator'] = '_'.join(fields[:pos])
-        elif head3 == 'Net' and tok[3:4].isdigit():
-            cfg['net_size'] = [int(v) for v in tok[3:].split('-')]
+        if head3 == 'Net' and tok[3:4].isdigit():
+            if all(v.isdigit() for v in tok[3:].split('-')):
+                cfg['net_size'] = [int(v) for v in tok[3:].split('-')]
         elif head1 == 'Q' and tok[1:].isdigit():
             cfg['num_qubits'] = int(tok[1:])
         elif tok in ('TF', 'FF', 'NTF'):
             cfg['if_trainable_freq'] = tok == 'TF'
-        elif head1 == 'S' and tok[1:2].isdigit():
+        elif head1 == 'S' and _NUMBER.fullmatch(tok[1:]):
             cfg['scale_coeff'] = float(tok[1:])
         elif tok.startswith('Pauli') and tok[5:] in ('X', 'Y', 'Z'):
             cfg['ham_pauli'] = tok[5:]
-        elif tok.startswith('Diag') and len(tok) > 4:
+        elif tok.startswith('Diag') and _signed_list(tok[4:]) is not None:
             cfg['ham_diag'] = _signed_list(tok[4:])
-        elif head3 == 'Ham' and len(tok) > 3:
+        elif head3 == 'Ham' and _signed_list(tok[3:]) is not None:
             cfg['ham_bound'] = _signed_list(tok[3:])
         elif tok.startswith('Seed') and tok[4:].isdigit():
             cfg['seed'] = int(tok[4:])
-        elif 'x' in tok and all(part.isdigit() for part in tok.split('x')) and tok.count('x') == 1:
+        elif tok.count('x') == 1 and all(part.isdigit() for part in tok.split('x')):
             cfg['num_train'], cfg['num_points'] = (int(v) for v in tok.split('x'))
-        elif tok in _BACKEND_TOKENS and 'model_type' in cfg:
+        elif tok in _BACKEND_TOKENS:
             cfg['quantum_backend'] = _BACKEND_TOKENS[tok]
+        # anything else (a field this grammar does not know, a malformed number) is skipped, never an error
     return cfg

@@ -133,8 +133,10 @@ def test_module_surface_matches_reference_contract(lib):
     with pytest.raises(ValueError):
         HEACircuitHIP(1, [(1, 1)])
     with pytest.raises(ValueError):
-        m.quantum_layer(torch.zeros(4, 7, dtype=torch.float64))
+        m.quantum_layer(torch.zeros(4, 7, 2, dtype=torch.float64))
     from quanonet_amd import _lib
+    with pytest.raises(_lib.QheaError):     # a narrower x is legal (the reference's column guard, tq.py:83) and reaches the op
+        m.quantum_layer(torch.zeros(4, 7, dtype=torch.float64))
     with pytest.raises(_lib.QheaError):                            # no CPU fallback
         m(torch.zeros(4, 100, dtype=torch.float64), torch.zeros(4, 2, dtype=torch.float64))
 

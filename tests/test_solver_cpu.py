@@ -132,6 +132,23 @@ def test_checkpoint_roundtrip_and_name_parsing(tmp_path):
         c = ck.parse_experiment_dir(nm)
         assert c['model_type'] == 'QuanONet' and len(c['net_size']) == 4 and c['if_trainable_freq'] is True
     assert ck.parse_experiment_dir('weights') == {}
+    # all four directory names under the reference's pretrained_weights/
+    for nm, n, pts in (('Antideriv_QuanONet_Net5-1-5-1_Q2_TF_S0.001_1000x100_Seed0', 2, 100),
+                       ('Advection_QuanONet_Net40-2-20-2_Q5_TF_S0.1_1000x100_Seed0', 5, 100),
+                       ('RDiffusion_QuanONet_Net40-2-20-2_Q5_TF_S0.1_1000x100_Seed0', 5, 100),
+                       ('Darcy_QuanONet_Net40-2-20-2_Q5_TF_S0.1_1000x25_Seed0', 5, 25)):
+        c = ck.parse_experiment_dir(nm)
+        assert (c['operator'], c['num_qubits'], c['num_points'], c['seed']) == (nm.split('_')[0], n, pts, 0)
+    # str(v) of small / negative values: exponent forms inside the dash-joined lists and the scale
+    c = ck.parse_experiment_dir('Op_QuanONet_Net2-1-2-1_Q2_TF_S1e-05_Diag1e-05--2.5-3.0-4e+02_10x5_Seed1')
+    assert c['scale_coeff'] == 1e-05 and c['ham_diag'] == [1e-05, -2.5, 3.0, 400.0]
+    assert ck.parse_experiment_dir('Op_HEAQNN_Net2-1_Q3_FF_S0.1_Ham-1e-05-2.5_10x5_Seed1')['ham_bound'] == [-1e-05, 2.5]
+    # an operator whose name has '_' parts that look like hyper-parameters does not overwrite them
+    c = ck.parse_experiment_dir('My_Q9_S7_Op_QuanONet_Net2-1-2-1_Q2_TF_S0.5_10x5_Seed1')
+    assert c['operator'] == 'My_Q9_S7_Op' and c['num_qubits'] == 2 and c['scale_coeff'] == 0.5
+    # malformed fields are skipped, not raised
+    c = ck.parse_experiment_dir('Op_QuanONet_Net2-1-2-1_Q2_TF_Sx_Diag1e-_Hamfoo_10x5_Seed1')
+    assert 'scale_coeff' not in c and 'ham_diag' not in c and 'ham_bound' not in c and c['seed'] == 1
     # MindSpore .ckpt reader against a protobuf written here (same wire layout as SURVEY.md 8c)
     def varint(v):
         out = b''
