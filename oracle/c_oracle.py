@@ -35,6 +35,8 @@ def lib():
         _LIB.qhea_oracle_backward.argtypes = [ctypes.c_int, ctypes.c_int, i32, i32, ctypes.c_int64,
                                               d, d, ctypes.c_double, ctypes.c_double, d, ctypes.c_int, d, d, d, d]
         _LIB.qhea_oracle_threads.restype = ctypes.c_int
+        _LIB.qhea_oracle_set_threads.restype = ctypes.c_int
+        _LIB.qhea_oracle_set_threads.argtypes = [ctypes.c_int]
     return _LIB
 
 
@@ -55,6 +57,11 @@ def _pauli(p):
 
 def threads():
     return lib().qhea_oracle_threads()
+
+
+def set_threads(n):
+    """OpenMP threads of the following calls; returns the previous maximum."""
+    return lib().qhea_oracle_set_threads(int(n))
 
 
 def _fit_columns(x, block_configs):

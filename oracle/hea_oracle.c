@@ -249,3 +249,15 @@ int qhea_oracle_threads(void) {
     return 1;
 #endif
 }
+
+/* number of OpenMP threads of the following calls (bench.py's 1-thread baseline leg); returns the previous maximum */
+int qhea_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    const int before = omp_get_max_threads();
+    if (n > 0) omp_set_num_threads(n);
+    return before;
+#else
+    (void)n;
+    return 1;
+#endif
+}

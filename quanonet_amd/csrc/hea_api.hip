@@ -7,6 +7,7 @@
 #include "hea_device.hpp"
 #include "hea_zyz.hpp"
 #include "hea_adam.hpp"
+#include "hea_dp.hpp"
 
 namespace qhea {
 
@@ -268,7 +269,9 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
                                                  bool poisoned, const double* gmap /* ZYZ-form sums, or nullptr (the fused path rewrites the block's own entries at its end) */,
                                                  const AdamArgs* adam = nullptr, long adam_base = 0,
                                                  int cols_block = 0 /* columns per block if not red_cols(kw) */,
-                                                 double* newp = nullptr /* LDS [cols_block / kw][3][n]: the block's angles after the update */) {
+                                                 double* newp = nullptr /* LDS [cols_block / kw][3][n]: the block's angles after the update */,
+                                                 const DpX* dp = nullptr /* data-parallel step: exchange this block's gradients before the update */,
+                                                 int* dp_failed = nullptr /* one int of LDS */) {
     // cols_block = 2 red_cols(kw) (fused path, two sub-layers per block): every thread sums TWO of the 64 row slices, so that
     // each column's additions are exactly those of the one-sub-layer blocks (acc then holds 2 kRedThreads values)
     const int cols = cols_block ? cols_block : red_cols(kw), nslices = kRedThreads / red_cols(kw);
@@ -314,41 +317,55 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
         acc[j] = t;
     }
     __syncthreads();
-    if (slice == 0 && v < ncols) {
-        const int s = (int)(v / kw), r = (int)(v % kw);
-        if (r < 3 * n && r % 3 == 0) {
-            const int q = r / 3;
-            double X = acc[j], Y = acc[j + 1];
-            const double Z = acc[j + 2];
-            const double* ws = w + (long)s * 3 * n;
-            double sb, cb, sc, cc;
-            if (gmap) {     // sums taken after the RY layer, before D_post = RZ(alpha): rotate (X, Y) by alpha (hea_zyz.hpp)
-                cb = gmv[0]; sb = gmv[1]; cc = gmv[2]; sc = gmv[3];
-                const double ca = gmv[4], sa = gmv[5];
-                const double Xr = ca * X - sa * Y;
-                Y = ca * Y + sa * X;
-                X = Xr;
-            } else {
-                sincos(ws[n + q], &sb, &cb);
-                sincos(ws[2 * n + q], &sc, &cc);
-            }
-            double* gs = grad_w + (long)s * 3 * n;
-            double gc = Y, gb = cc * Z + sc * X, ga = cb * Y - sb * cc * X + sb * sc * Z;
-            if (poisoned) gc = gb = ga = std::numeric_limits<double>::quiet_NaN();   // the circuit kernel reported an overrun
-            gs[2 * n + q] = gc;
-            gs[n + q] = gb;
-            gs[q] = ga;
-            double pn[3] = {ap[0], ap[1], ap[2]};
-            if (upd && !poisoned) {              // this thread alone reads and writes the three angles of gate (s, q)
-                const long base = adam_base + (long)s * 3 * n;
-                pn[2] = adam_update_pre(*adam, base + 2 * n + q, gc, ap[2], am[2], av[2]);
-                pn[1] = adam_update_pre(*adam, base + n + q, gb, ap[1], am[1], av[1]);
-                pn[0] = adam_update_pre(*adam, base + q, ga, ap[0], am[0], av[0]);
-            }
-            if (newp) {                          // (only with an update pending: ap holds the current angles)
-                double* np = newp + (long)(s - (int)((long)bid * cols / kw)) * 3 * n;
-                np[q] = pn[0]; np[n + q] = pn[1]; np[2 * n + q] = pn[2];
-            }
+    // the thread that finishes gate (s, q): local gradients of its three angles, then -- data-parallel step -- their sum over
+    // the ranks (every thread of the block takes part in the flag / wait phase), then the update
+    double gc = 0.0, gb = 0.0, ga = 0.0;
+    const int s = (int)(v / kw), q = q_fin;
+    if (fin) {
+        double X = acc[j], Y = acc[j + 1];
+        const double Z = acc[j + 2];
+        const double* ws = w + (long)s * 3 * n;
+        double sb, cb, sc, cc;
+        if (gmap) {     // sums taken after the RY layer, before D_post = RZ(alpha): rotate (X, Y) by alpha (hea_zyz.hpp)
+            cb = gmv[0]; sb = gmv[1]; cc = gmv[2]; sc = gmv[3];
+            const double ca = gmv[4], sa = gmv[5];
+            const double Xr = ca * X - sa * Y;
+            Y = ca * Y + sa * X;
+            X = Xr;
+        } else {
+            sincos(ws[n + q], &sb, &cb);
+            sincos(ws[2 * n + q], &sc, &cc);
+        }
+        gc = Y; gb = cc * Z + sc * X; ga = cb * Y - sb * cc * X + sb * sc * Z;
+        if (poisoned) gc = gb = ga = std::numeric_limits<double>::quiet_NaN();   // the circuit kernel reported an overrun
+    }
+    bool skip = poisoned;
+    if (dp) {           // (block-uniform)
+        const long base = adam_base + (long)s * 3 * n;     // index in the flat [gradients | sse | sum y^2] vector
+        if (fin) { dpx_publish(*dp, base + 2 * n + q, gc); dpx_publish(*dp, base + n + q, gb); dpx_publish(*dp, base + q, ga); }
+        const int blk_id = bid;
+        const bool ok = dpx_flags_and_wait(*dp, [blk_id](char* buf, int r) { return dp_bflag(buf, r, blk_id); }, dp_failed);
+        if (fin) {
+            if (ok) { gc = dpx_collect(*dp, base + 2 * n + q); gb = dpx_collect(*dp, base + n + q); ga = dpx_collect(*dp, base + q); }
+            else gc = gb = ga = std::numeric_limits<double>::quiet_NaN();
+            skip = !(gc == gc && gb == gb && ga == ga);     // some rank's NaN (its pipeline overran) or a failed exchange: no update anywhere
+        }
+    }
+    if (fin) {
+        double* gs = grad_w + (long)s * 3 * n;
+        gs[2 * n + q] = gc;
+        gs[n + q] = gb;
+        gs[q] = ga;
+        double pn[3] = {ap[0], ap[1], ap[2]};
+        if (upd && !skip) {                  // this thread alone reads and writes the three angles of gate (s, q)
+            const long base = adam_base + (long)s * 3 * n;
+            pn[2] = adam_update_pre(*adam, base + 2 * n + q, gc, ap[2], am[2], av[2]);
+            pn[1] = adam_update_pre(*adam, base + n + q, gb, ap[1], am[1], av[1]);
+            pn[0] = adam_update_pre(*adam, base + q, ga, ap[0], am[0], av[0]);
+        }
+        if (newp) {                          // (only with an update pending: ap holds the current angles)
+            double* np = newp + (long)(s - (int)((long)bid * cols / kw)) * 3 * n;
+            np[q] = pn[0]; np[n + q] = pn[1]; np[2 * n + q] = pn[2];
         }
     }
 }
@@ -678,21 +695,27 @@ struct FusePrep {
     char* rec; char* srec; double* gmap;
 };
 constexpr int kFuseMaxLd = 2;
-template <bool FUSE>        // (two instantiations: the fused one's LDS and registers do not weigh on the plain one)
+// DP (the data-parallel step, qhea_model_dp_train_steps): every block publishes the LOCAL gradients it has just formed to
+// the peers' exchange buffers, waits for the peers' (flags per block), adds them in rank order and only then writes the
+// gradient row, updates and -- FUSE -- writes the next records: the sum over the ranks costs no launch of its own
+// (hea_dp.hpp; bitwise the results of qhea_model_loss_grad + qhea_dp_allreduce_adam).
+template <bool FUSE, bool DP>        // (the fused one's LDS and registers do not weigh on the plain one)
 __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         int n, int blk, int kw, long nwaves, const double* __restrict__ partial, const double* w,
         long B, int E, EncDesc enc, const double* __restrict__ grad_x, const double* __restrict__ pred,
         const double* __restrict__ y, double inv_bt, GradMap gm, int nb_w, int nb_x, double* __restrict__ grad,
-        AdamArgs adam, const WorkspaceHeader* __restrict__ hdr, const double* gmap, FusePrep fp) {
+        AdamArgs adam, const WorkspaceHeader* __restrict__ hdr, const double* gmap, FusePrep fp, DpX dpx) {
     __shared__ double acc[kRedThreads];
     __shared__ double acc2[kRedThreads];
+    __shared__ int dp_failed;
     const int bid = blockIdx.x;
+    const DpX* dp = DP ? &dpx : nullptr;
     if constexpr (FUSE) if (bid < nb_w) {           // (block-uniform)
         __shared__ PrepShared psh[kFuseMaxLd + 1];
         __shared__ double newp[kFuseMaxLd * 3 * QHEA_MAX_QUBITS];
         __shared__ double accbig[2 * kRedThreads];
         reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, accbig, hdr->status != 0, gmap, &adam,
-                         gm.off_ans, fp.ld * kw, newp);
+                         gm.off_ans, fp.ld * kw, newp, dp, &dp_failed);
         __syncthreads();
         const int grp = (int)threadIdx.x >> 6, j = (int)threadIdx.x & 63;
         const int per = 1 + fp.ld, s0 = bid * fp.ld;
@@ -708,7 +731,8 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
     const unsigned status = hdr->status;
     const double kNaN = std::numeric_limits<double>::quiet_NaN();
     if (bid < nb_w) {
-        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, status != 0, gmap, &adam, gm.off_ans);
+        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, status != 0, gmap, &adam, gm.off_ans,
+                         0, nullptr, dp, &dp_failed);
     } else if (bid < nb_w + nb_x) {
         const int j = threadIdx.x % kFreqCols, slice = threadIdx.x / kFreqCols;
         const int e = (bid - nb_w) * kFreqCols + j;
@@ -749,14 +773,26 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         }
         acc[slice * kFreqCols + j] = s0; acc2[slice * kFreqCols + j] = s1;
         __syncthreads();
-        if (slice == 0 && e < E && gm.off_w[si] >= 0) {
-            double t0 = 0.0, t1 = 0.0;
+        const bool mine = slice == 0 && e < E && gm.off_w[si] >= 0;
+        double t0 = 0.0, t1 = 0.0;
+        bool skip = status != 0;
+        if (mine) {
             for (int i = 0; i < kFreqSlices; ++i) { t0 += acc[i * kFreqCols + j]; t1 += acc2[i * kFreqCols + j]; }
-            const bool poisoned = status != 0;
-            if (poisoned) t0 = t1 = kNaN;
+            if (skip) t0 = t1 = kNaN;
+        }
+        if constexpr (DP) {
+            if (mine) { dpx_publish(dpx, gm.off_b[si] + ee, t0); dpx_publish(dpx, gm.off_w[si] + ee, t1); }
+            const bool ok = dpx_flags_and_wait(dpx, [bid](char* buf, int r) { return dp_bflag(buf, r, bid); }, &dp_failed);
+            if (mine) {
+                t0 = ok ? dpx_collect(dpx, gm.off_b[si] + ee) : kNaN;
+                t1 = ok ? dpx_collect(dpx, gm.off_w[si] + ee) : kNaN;
+                skip = !(t0 == t0 && t1 == t1);
+            }
+        }
+        if (mine) {
             grad[gm.off_b[si] + ee] = t0;
             grad[gm.off_w[si] + ee] = t1;
-            if (adam.p && !poisoned) { adam_update(adam, gm.off_b[si] + ee, t0); adam_update(adam, gm.off_w[si] + ee, t1); }
+            if (adam.p && !skip) { adam_update(adam, gm.off_b[si] + ee, t0); adam_update(adam, gm.off_w[si] + ee, t1); }
         }
     } else {
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -775,14 +811,28 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
             }
             __syncthreads();
         }
+        const bool poisoned = status != 0;
+        double sse = poisoned ? kNaN : acc[0], sy2 = red3[0], gbias = poisoned ? kNaN : 2.0 * inv_bt * acc2[0];
+        bool skip = poisoned;
+        if constexpr (DP) {
+            if (threadIdx.x == 0) {
+                dpx_publish(dpx, gm.off_sse, sse); dpx_publish(dpx, gm.off_sse + 1, sy2);
+                if (gm.off_bias >= 0) dpx_publish(dpx, gm.off_bias, gbias);
+            }
+            const bool ok = dpx_flags_and_wait(dpx, [bid](char* buf, int r) { return dp_bflag(buf, r, bid); }, &dp_failed);
+            if (threadIdx.x == 0) {
+                sse = ok ? dpx_collect(dpx, gm.off_sse) : kNaN;
+                sy2 = ok ? dpx_collect(dpx, gm.off_sse + 1) : kNaN;
+                if (gm.off_bias >= 0) gbias = ok ? dpx_collect(dpx, gm.off_bias) : kNaN;
+                skip = !(gbias == gbias) || !ok;
+            }
+        }
         if (threadIdx.x == 0) {
-            const bool poisoned = status != 0;
-            grad[gm.off_sse] = poisoned ? kNaN : acc[0];
-            grad[gm.off_sse + 1] = red3[0];
+            grad[gm.off_sse] = sse;
+            grad[gm.off_sse + 1] = sy2;
             if (gm.off_bias >= 0) {
-                const double gbias = poisoned ? kNaN : 2.0 * inv_bt * acc2[0];
                 grad[gm.off_bias] = gbias;
-                if (adam.p && !poisoned) adam_update(adam, gm.off_bias, gbias);
+                if (adam.p && !skip) adam_update(adam, gm.off_bias, gbias);
             }
         }
     }
@@ -897,7 +947,7 @@ using namespace qhea;
 
 extern "C" {
 
-int qhea_version(void) { return 420; }
+int qhea_version(void) { return 430; }
 
 const char* qhea_strerror(int code) {
     switch (code) {
@@ -1130,18 +1180,43 @@ static bool model_fuse_eligible(const ModelInfo& mi, const Layout& L) {
     return (L.ztri || L.zpacked) && ld >= 1 && ld <= kFuseMaxLd && (cols == 16 || cols == 32) && mi.sh.blk % ld == 0;
 }
 
+// reduce launch of the model-level calls: FUSE = also writes the next step's records, dpx = exchanges with the peer ranks
+static int launch_reduce_model(int nblocks, hipStream_t st, const ModelInfo& mi, int kw, long nwaves, const double* partial,
+                               const double* params, int64_t batch, const EncDesc& enc, const double* gx, const double* pr,
+                               const double* y, double inv_bt, const GradMap& gm, int nb_w, int nb_x, double* grad,
+                               const AdamArgs& adam, const char* ws, const double* gmap, const FusePrep& fp, const DpX* dpx) {
+    const DpX none{};
+    const DpX& dx = dpx ? *dpx : none;
+    const dim3 g((unsigned)nblocks), b(kRedThreads);
+    const WorkspaceHeader* hdr = reinterpret_cast<const WorkspaceHeader*>(ws);
+#define QHEA_LAUNCH_REDUCE(F, D)                                                                                          \
+    hipLaunchKernelGGL((reduce_model_kernel<F, D>), g, b, 0, st, mi.n, (int)mi.sh.blk, kw, nwaves, partial, params + mi.off_ans, \
+                       (long)batch, (int)mi.sh.E, enc, gx, pr, y, inv_bt, gm, nb_w, nb_x, grad, adam, hdr, gmap, fp, dx)
+    if (fp.ld != 0) { if (dpx) QHEA_LAUNCH_REDUCE(true, true); else QHEA_LAUNCH_REDUCE(true, false); }
+    else            { if (dpx) QHEA_LAUNCH_REDUCE(false, true); else QHEA_LAUNCH_REDUCE(false, false); }
+#undef QHEA_LAUNCH_REDUCE
+    return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+}
+
+// a data-parallel reduce launch needs every block resident at once (its blocks wait for the peers' blocks) and a flag
+// per block in the exchange buffers
+static bool dp_blocks_ok(int nblocks) { return nblocks <= kDpMaxBlocks && nblocks <= simd_count() / 4; }
+
 static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
                                 const double* y, const double* params, const double* ham_diag, double inv_batch_total,
                                 double* grad, double* pred, void* workspace, size_t workspace_bytes, void* stream,
-                                const AdamArgs& adam, bool records_ready = false, bool records_for_next = false) {
+                                const AdamArgs& adam, bool records_ready = false, bool records_for_next = false,
+                                const DpX* dpx = nullptr) {
     // records_ready / records_for_next (qhea_model_train_steps only): the previous step's reduce kernel has written this
-    // step's layer records / this step's reduce kernel writes the next step's (FusePrep)
+    // step's layer records / this step's reduce kernel writes the next step's (FusePrep).  dpx (qhea_model_dp_train_steps):
+    // the reduce kernel's blocks exchange their gradients with the peer ranks before they update.
     ModelInfo mi;
     int rc = model_info(desc, mi);
     if (rc != QHEA_OK) return rc;
     if (batch < 0 || !grad || !pauli_ok(desc->ham_pauli, ham_diag)) return QHEA_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (batch == 0) {
+        if (dpx) return QHEA_EUNSUPPORTED;                      // (an empty shard still owes the peers its zeros: caller's path)
         return hipMemsetAsync(grad, 0, sizeof(double) * (mi.P + 2), st) == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
     }
     if (!branch || !params || !y || (desc->model == QHEA_MODEL_QUANONET && !trunk)) return QHEA_EINVAL;
@@ -1168,6 +1243,7 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
             fp.gmap = reinterpret_cast<double*>(ws + M.L.off_gmap);
             nb_w = (int)(mi.sh.blk / fp.ld);                   // one reduce block per circuit block
         }
+        if (dpx && !dp_blocks_ok(nb_w + nb_x + 1)) return QHEA_EUNSUPPORTED;
         if (!records_ready) {
             rc = launch_prep_zyz(mi.n, mi.sh, params + mi.off_ans, ws, M.L, st);
             if (rc != QHEA_OK) return rc;
@@ -1179,19 +1255,12 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
         profile_end(st);
         if (rc != QHEA_OK) return rc;
         if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
-        if (fp.ld != 0)
-            hipLaunchKernelGGL(reduce_model_kernel<true>, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
-                               (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
-                               gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws),
-                               reinterpret_cast<const double*>(ws + M.L.off_gmap), fp);
-        else
-            hipLaunchKernelGGL(reduce_model_kernel<false>, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
-                               (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
-                               gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws),
-                               reinterpret_cast<const double*>(ws + M.L.off_gmap), fp);
-        return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+        return launch_reduce_model(nb_w + nb_x + 1, st, mi, kw, M.L.nwaves, partial, params, batch, enc, gx, pr, y,
+                                   inv_batch_total, gm, nb_w, nb_x, grad, adam, ws,
+                                   reinterpret_cast<const double*>(ws + M.L.off_gmap), fp, dpx);
     }
     if (records_ready || records_for_next) return QHEA_EINVAL;
+    if (dpx && !dp_blocks_ok(nb_w + nb_x + 1)) return QHEA_EUNSUPPORTED;
     rc = launch_prep_model(mi, batch, params, enc, ws, M.L, st);
     if (rc != QHEA_OK) return rc;
     const dim3 grid((unsigned)(M.L.nwaves / kWaves));
@@ -1212,11 +1281,8 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
     }
     profile_end(st);
     if (hipGetLastError() != hipSuccess) return QHEA_ELAUNCH;
-    hipLaunchKernelGGL(reduce_model_kernel<false>, dim3((unsigned)(nb_w + nb_x + 1)), dim3(kRedThreads), 0, st, mi.n,
-                       (int)mi.sh.blk, kw, M.L.nwaves, partial, params + mi.off_ans, (long)batch, (int)mi.sh.E, enc,
-                       gx, pr, y, inv_batch_total, gm, nb_w, nb_x, grad, adam, reinterpret_cast<const WorkspaceHeader*>(ws),
-                       static_cast<const double*>(nullptr), FusePrep{});
-    return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
+    return launch_reduce_model(nb_w + nb_x + 1, st, mi, kw, M.L.nwaves, partial, params, batch, enc, gx, pr, y, inv_batch_total,
+                               gm, nb_w, nb_x, grad, adam, ws, nullptr, FusePrep{}, dpx);
 }
 
 int qhea_model_forward(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
@@ -1305,6 +1371,63 @@ int qhea_model_train_steps(const qhea_model_desc* desc, int64_t n_steps, const i
                                             has_trunk ? trunk + r0 * desc->trunk_in : nullptr, y + r0, params, ham_diag,
                                             inv_batch_total[i], grad + i * grad_stride, nullptr, workspace, workspace_bytes,
                                             stream, adam, ready, next);
+        if (rc != QHEA_OK) return rc;
+        ready = next;
+    }
+    return QHEA_OK;
+}
+
+int qhea_model_dp_train_steps(const qhea_model_desc* desc, int64_t n_steps, const int64_t* row_begin,
+                              const double* branch, const double* trunk, const double* y, double* params,
+                              const double* ham_diag, const double* inv_batch_total, double* grad, int64_t grad_stride,
+                              double* exp_avg, double* exp_avg_sq, int64_t first_step, double lr, double beta1,
+                              double beta2, double eps, double weight_decay, int rank, int world, void* const* buffers,
+                              int64_t dp_values, int64_t first_seq, double timeout_ms, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    if (!desc || n_steps < 0 || !row_begin || !inv_batch_total || !branch || !y || !grad || first_step < 1)
+        return QHEA_EINVAL;
+    if (world < 2 || world > QHEA_DP_MAX_RANKS || rank < 0 || rank >= world || !buffers || first_seq < 1 || !(timeout_ms > 0.0))
+        return QHEA_EINVAL;
+    ModelInfo mi;
+    const int rc0 = model_info(desc, mi);
+    if (rc0 != QHEA_OK) return rc0;
+    if (grad_stride < mi.P + 2 || dp_values < mi.P + 2) return QHEA_EINVAL;
+    const bool has_trunk = desc->model == QHEA_MODEL_QUANONET;
+    if (has_trunk && !trunk) return QHEA_EINVAL;
+    if (!params || !exp_avg || !exp_avg_sq) return QHEA_EINVAL;
+    DpX dx{};
+    for (int r = 0; r < world; ++r) {
+        if (!buffers[r]) return QHEA_EINVAL;
+        dx.bufs[r] = static_cast<char*>(buffers[r]);
+    }
+    dx.rank = rank; dx.world = world; dx.npad = dp_padded((long)dp_values);
+    dx.timeout_ticks = (long long)(timeout_ms * 1e5);           // wall_clock64: 100 MHz
+    // every step must be launchable BEFORE the first one is (a rank that stops half-way would leave its peers waiting):
+    // no empty shard, and a reduce grid that fits the device and the exchange buffers' block flags
+    for (int64_t i = 0; i < n_steps; ++i) {
+        if (row_begin[i] < 0 || row_begin[i + 1] < row_begin[i]) return QHEA_EINVAL;
+        if (row_begin[i + 1] == row_begin[i]) return QHEA_EUNSUPPORTED;
+    }
+    {
+        const int kw = padded_3n(mi.n);
+        const int nb_x = mi.trainable ? (int)((mi.sh.E + kFreqCols - 1) / kFreqCols) : 0;
+        const int nb_w = (int)((mi.sh.blk * kw + red_cols(kw) - 1) / red_cols(kw));     // (the fused reduce uses fewer)
+        if (!dp_blocks_ok(nb_w + nb_x + 1)) return QHEA_EUNSUPPORTED;
+    }
+    bool ready = false;
+    for (int64_t i = 0; i < n_steps; ++i) {
+        const int64_t r0 = row_begin[i], nb = row_begin[i + 1] - r0;
+        bool next = false;
+        if (i + 1 < n_steps && row_begin[i + 2] - row_begin[i + 1] == nb)
+            next = model_fuse_eligible(mi, make_model_layout(mi, nb).L);
+        const int64_t step = first_step + i;
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        const AdamArgs adam{params, exp_avg, exp_avg_sq, lr / bc1, 1.0 / sqrt(bc2), beta1, beta2, eps, weight_decay};
+        dx.seq = (unsigned long long)(first_seq + i);
+        const int rc = model_loss_grad_impl(desc, nb, branch + r0 * desc->branch_in,
+                                            has_trunk ? trunk + r0 * desc->trunk_in : nullptr, y + r0, params, ham_diag,
+                                            inv_batch_total[i], grad + i * grad_stride, nullptr, workspace, workspace_bytes,
+                                            stream, adam, ready, next, &dx);
         if (rc != QHEA_OK) return rc;
         ready = next;
     }

@@ -18,83 +18,44 @@
 // a rank can be at most one exchange ahead of the slowest rank (its next collect needs everybody's next flag, which a
 // rank only sets after it has finished reading the previous slots), so seq + 1 never overwrites what a peer still reads.
 // A wait that overruns its bound poisons the output with NaN, skips the Adam update and raises an error word that
-// qhea_dp_status reports -- it never computes through a missing contribution.
+// qhea_dp_status reports -- it never computes through a missing contribution -- and it raises the sticky poison word in
+// EVERY rank's header, so that the late rank and every later exchange fail too (hea_dp.hpp).  The buffer layout and the
+// device side of the exchange live in hea_dp.hpp, shared with the reduce kernel of the data-parallel training step
+// (hea_api.hip: qhea_model_dp_train_steps), whose blocks exchange their own columns.
 #include <cmath>
 #include <cstring>
 #include <limits>
 
 #include "hea_adam.hpp"
+#include "hea_dp.hpp"
 #include "quanonet_hea.h"
 
 namespace qhea {
 namespace {
 
 constexpr int kDpThreads = 1024;
-constexpr size_t kDpHeaderBytes = 256;
-
-struct DpHeader {
-    unsigned long long flag[QHEA_DP_MAX_RANKS];      // flag[r] = seq of the last exchange rank r has published here
-    unsigned int error;                              // bit 0: a collect wait overran its bound
-};
-static_assert(sizeof(DpHeader) <= kDpHeaderBytes, "header");
-
-__host__ __device__ inline long padded_values(long n) { return (n + 1) & ~1L; }
-__host__ __device__ inline size_t dp_bytes(long n, int world) {
-    return kDpHeaderBytes + (size_t)2 * world * padded_values(n) * sizeof(double);
-}
-__device__ __forceinline__ double* slot(char* buf, int parity, int world, int r, long npad) {
-    return reinterpret_cast<double*>(buf + kDpHeaderBytes) + ((long)parity * world + r) * npad;
-}
 
 struct DpArgs {
-    char* bufs[QHEA_DP_MAX_RANKS];                   // every rank's exchange buffer as mapped in THIS process
-    int rank, world;
+    DpX x;
     long n, n_adam;                                  // values exchanged; the first n_adam of them are parameters' gradients
-    unsigned long long seq;
     const double* local;
     double* out;
     AdamArgs adam;
-    long long timeout_ticks;                         // of wall_clock64() (100 MHz)
 };
 
 __global__ __launch_bounds__(kDpThreads) void dp_exchange_kernel(DpArgs a) {
-    const int tid = threadIdx.x, parity = (int)(a.seq & 1);
-    const long npad = padded_values(a.n);
+    const int tid = threadIdx.x;
     __shared__ int failed;
-    if (tid == 0) failed = 0;
     // ---- publish: this rank's values into slot [parity][rank] of every rank's buffer (own included)
-    for (long i = tid; i < a.n; i += kDpThreads) {
-        const double v = a.local[i];
-        for (int p = 0; p < a.world; ++p)
-            __hip_atomic_store(slot(a.bufs[p], parity, a.world, a.rank, npad) + i, v, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: every store above has left this device
-    __syncthreads();
-    if (tid < a.world)
-        __hip_atomic_store(&reinterpret_cast<DpHeader*>(a.bufs[tid])->flag[a.rank], a.seq, __ATOMIC_RELEASE,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    // ---- collect: wait for everybody's flag in the own header
-    char* own = a.bufs[a.rank];
-    if (tid < a.world) {
-        const unsigned long long* f = &reinterpret_cast<DpHeader*>(own)->flag[tid];
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
-            if (wall_clock64() - t0 > a.timeout_ticks) { failed = 1; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __syncthreads();
-    if (failed) {
-        if (tid == 0) atomicOr(&reinterpret_cast<DpHeader*>(own)->error, 1u);
+    for (long i = tid; i < a.n; i += kDpThreads) dpx_publish(a.x, i, a.local[i]);
+    // ---- flags out, then wait for everybody's flag in the own header
+    const bool ok = dpx_flags_and_wait(a.x, [](char* buf, int r) { return &reinterpret_cast<DpHeader*>(buf)->flag[r]; }, &failed);
+    if (!ok) {
         for (long i = tid; i < a.n; i += kDpThreads) a.out[i] = std::numeric_limits<double>::quiet_NaN();
         return;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     for (long i = tid; i < a.n; i += kDpThreads) {
-        double s = 0.0;
-        for (int r = 0; r < a.world; ++r)                    // rank order on every rank: bitwise identical replicas
-            s += __hip_atomic_load(slot(own, parity, a.world, r, npad) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const double s = dpx_collect(a.x, i);                // rank order on every rank: bitwise identical replicas
         a.out[i] = s;
         if (a.adam.p && i < a.n_adam) adam_update(a.adam, i, s);
     }
@@ -173,11 +134,12 @@ int qhea_dp_allreduce_adam(int rank, int world, void* const* buffers, int64_t n_
     DpArgs a{};
     for (int r = 0; r < world; ++r) {
         if (!buffers[r]) return QHEA_EINVAL;
-        a.bufs[r] = static_cast<char*>(buffers[r]);
+        a.x.bufs[r] = static_cast<char*>(buffers[r]);
     }
-    a.rank = rank; a.world = world; a.n = (long)n_values; a.n_adam = (long)n_params;
-    a.seq = (unsigned long long)seq; a.local = local; a.out = out;
-    a.timeout_ticks = (long long)(timeout_ms * 1e5);         // wall_clock64: 100 MHz
+    a.x.rank = rank; a.x.world = world; a.x.npad = dp_padded((long)n_values);
+    a.x.seq = (unsigned long long)seq;
+    a.x.timeout_ticks = (long long)(timeout_ms * 1e5);       // wall_clock64: 100 MHz
+    a.n = (long)n_values; a.n_adam = (long)n_params; a.local = local; a.out = out;
     if (params) {
         if (!exp_avg || !exp_avg_sq || step < 1) return QHEA_EINVAL;
         const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
@@ -190,13 +152,13 @@ int qhea_dp_allreduce_adam(int rank, int world, void* const* buffers, int64_t n_
 int qhea_dp_status(void* buffer, void* stream) {
     if (!buffer) return QHEA_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    unsigned int err = 0;
+    unsigned int err[2] = {0, 0};                            // error (cleared here), poison (sticky)
     unsigned int* dev = &static_cast<DpHeader*>(buffer)->error;
-    if (hipMemcpyAsync(&err, dev, sizeof err, hipMemcpyDeviceToHost, st) != hipSuccess ||
+    if (hipMemcpyAsync(err, dev, sizeof err, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
         return QHEA_ELAUNCH;
-    if (err == 0) return QHEA_OK;
-    (void)hipMemsetAsync(dev, 0, sizeof err, st);
+    if (err[0] == 0 && err[1] == 0) return QHEA_OK;
+    (void)hipMemsetAsync(dev, 0, sizeof(unsigned int), st);
     (void)hipStreamSynchronize(st);
     return QHEA_EEXCHANGE;
 }

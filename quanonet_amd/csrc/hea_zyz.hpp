@@ -802,7 +802,7 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
             const char* row = reinterpret_cast<const char*>(cs) + (role * (int)zyz_cs_row(5, E) + 5) * 32;
             const double x = zsplit_forward<MODE>(ss, row, a.nblocks, lane, ring_fwd);
             reinterpret_cast<double*>(psi_final)[(((role << 5) | (lane & 31)) << 1) | (lane >> 5)] = x;   // all-lane layout
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            handoff_release();
             if (lane == 0) __hip_atomic_fetch_add(&sync->ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             swept = true;
         }
@@ -852,7 +852,7 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
         }
         ring[step & (RING - 1)][lane] = make_double2(sr[0], si[0]);
         ++step;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS executes a wave's instructions in order
+        handoff_release();                                   // hea_device.hpp: data before counter, s_waitcnt lgkmcnt(0)
         __hip_atomic_store(prod, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
