@@ -314,8 +314,37 @@ int qhea_dp_allreduce_adam(int rank, int world, void* const* buffers /*HOST arra
                            int64_t n_params, double* params /*DEVICE or NULL*/, double* exp_avg, double* exp_avg_sq,
                            int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay,
                            double timeout_ms, void* stream);
-/* waits for `stream`; QHEA_EEXCHANGE if an exchange on this buffer timed out since the last call (and clears it) */
+/*
+ * waits for `stream`; QHEA_EEXCHANGE if an exchange on this buffer failed since the last call.  A timeout is fatal on
+ * EVERY rank: the rank whose wait overran raises a sticky word in every rank's buffer, and from then on every exchange on
+ * these buffers -- the late rank's included -- fails (NaN results, no update) and this call keeps returning
+ * QHEA_EEXCHANGE; the replicas cannot drift apart silently.  Free and re-create the buffers to start over.
+ */
 int qhea_dp_status(void* buffer /*DEVICE: this rank's own*/, void* stream);
+
+/*
+ * The data-parallel training step with the exchange INSIDE the reduce kernel: qhea_model_train_steps for `world` ranks.
+ * Step i of this rank trains on its shard rows [row_begin[i], row_begin[i+1]) (never empty) with residual weight
+ * inv_batch_total[i] = 1 / GLOBAL batch; every block of the step's reduce kernel publishes the gradients it has just
+ * summed to the peers' exchange buffers (exchange number first_seq + i; the qhea_dp_* buffers above, allocated for
+ * dp_values >= P + 2 doubles), waits for the peers' blocks, adds the contributions in rank order, leaves the GLOBAL
+ * [gradients | sse | sum y^2] in grad + i*grad_stride, applies Adam and -- between steps of equal shard size on the
+ * block-unrolled shapes -- writes the next step's layer records: two launches per step (circuit, reduce) instead of
+ * prep + circuit + reduce + exchange.  Bitwise the results of qhea_model_loss_grad + qhea_dp_allreduce_adam.  Replaces the
+ * `loss.backward(); all_reduce; optimizer.step()` a DistributedDataParallel port of solvers/solver_pt.py:232-237 would run.
+ * Returns QHEA_EUNSUPPORTED -- before anything is launched -- when a shard is empty or the reduce grid would not be
+ * resident at once (more blocks than CUs, or than block flags in the buffers): use qhea_model_loss_grad +
+ * qhea_dp_allreduce_adam for such a run.  Failure semantics as qhea_dp_allreduce_adam / qhea_dp_status.
+ */
+int qhea_model_dp_train_steps(const qhea_model_desc* desc, int64_t n_steps, const int64_t* row_begin /*HOST [n_steps+1]*/,
+                              const double* branch, const double* trunk, const double* y, double* params,
+                              const double* ham_diag, const double* inv_batch_total /*HOST [n_steps]*/,
+                              double* grad /*DEVICE [n_steps, grad_stride]*/, int64_t grad_stride,
+                              double* exp_avg, double* exp_avg_sq, int64_t first_step, double lr, double beta1,
+                              double beta2, double eps, double weight_decay,
+                              int rank, int world, void* const* buffers /*HOST array of DEVICE pointers*/,
+                              int64_t dp_values, int64_t first_seq, double timeout_ms,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,16 @@ import os
 
 import torch
 
+# Inter-process mapping of the data-parallel exchange buffers (qhea_dp_export / qhea_dp_import = hipIpcGetMemHandle /
+# hipIpcOpenMemHandle) needs the dmabuf IPC mode on this driver stack: with the legacy mode hipIpcGetMemHandle fails with
+# "invalid argument" and the trainer would fall back to the RCCL all-reduce.  The HSA runtime reads the variable when it
+# is initialised, so the default is set here, at import, before this package makes its first HIP call; a process that had
+# already initialised the GPU without it is told so by PeerExchange.create (its reason string).
+IPC_ENV = 'HSA_ENABLE_IPC_MODE_LEGACY'
+IPC_ENV_PRESET = os.environ.get(IPC_ENV)
+IPC_ENV_SET_LATE = IPC_ENV_PRESET is None and torch.cuda.is_initialized()
+os.environ.setdefault(IPC_ENV, '0')
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('QHEA_LIB') or os.path.join(_HERE, 'libquanonet_hea.so')   # QHEA_LIB: ablation/dev builds
 
@@ -19,7 +29,7 @@ EXPORTS = ['qhea_version', 'qhea_strerror', 'qhea_device_count', 'qhea_workspace
            'qhea_profile_next_circuit_kernel',
            'qhea_adam_step', 'qhea_set_backward_variant', 'qhea_check_status',
            'qhea_dp_buffer_bytes', 'qhea_dp_alloc', 'qhea_dp_free', 'qhea_dp_export', 'qhea_dp_import', 'qhea_dp_close',
-           'qhea_dp_allreduce_adam', 'qhea_dp_status']
+           'qhea_dp_allreduce_adam', 'qhea_dp_status', 'qhea_model_dp_train_steps']
 
 
 class ModelDesc(ctypes.Structure):
@@ -31,7 +41,7 @@ class ModelDesc(ctypes.Structure):
 
 
 MODEL_QUANONET, MODEL_HEAQNN = 0, 1
-MIN_LIB_VERSION = 420           # 0.4.2: + the data-parallel exchange (qhea_dp_*)
+MIN_LIB_VERSION = 430           # 0.4.3: + qhea_model_dp_train_steps (exchange inside the reduce kernel)
 BWD_VARIANTS = {'auto': 0, 'packed': 1, 'pair': 2, 'tri': 3, 'ztri': 4, 'zpacked': 5, 'ztri2': 6}
 PAULI = {'Z': 0, 'X': 1, 'Y': 2}
 
@@ -119,6 +129,11 @@ def load():
                                            ctypes.c_double, vp]
     lib.qhea_dp_status.restype = ctypes.c_int
     lib.qhea_dp_status.argtypes = [vp, vp]
+    lib.qhea_model_dp_train_steps.restype = ctypes.c_int
+    lib.qhea_model_dp_train_steps.argtypes = [mdp, ctypes.c_int64, i64p, dp, dp, dp, dp, dp, f64p, dp, ctypes.c_int64, dp, dp,
+                                              ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                              ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, vpp,
+                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_double, vp, ctypes.c_size_t, vp]
     lib.qhea_model_param_count.restype = ctypes.c_int64
     lib.qhea_model_param_count.argtypes = [mdp]
     lib.qhea_model_workspace_bytes.restype = ctypes.c_size_t
@@ -413,6 +428,53 @@ def model_train_steps(desc, bounds, global_batches, branch, trunk, y, params, ro
                                         _ptr(exp_avg_sq), int(first_step), float(lr), float(beta1), float(beta2),
                                         float(eps), float(weight_decay), _ptr(ws), ws.numel(), _stream(branch.device))
     _check(rc, 'qhea_model_train_steps')
+    return rows
+
+
+class Unsupported(QheaError):
+    """QHEA_EUNSUPPORTED from a call that checks before it launches: the caller takes its other path."""
+
+
+def model_dp_train_steps(desc, bounds, global_batches, branch, trunk, y, params, rows, exp_avg, exp_avg_sq, first_step, lr,
+                         beta1, beta2, eps, weight_decay, rank, world, buffers, dp_values, first_seq, timeout_ms=5000.0,
+                         ham_diag=None):
+    """
+    model_train_steps for `world` ranks with the sum over the ranks inside each step's reduce kernel
+    (qhea_model_dp_train_steps): this rank's shard rows bounds[i]:bounds[i+1] per step, exchange numbers first_seq + i on the
+    peer-mapped `buffers`; rows[i] receives the GLOBAL [grads | sse | sum y^2].  Raises Unsupported -- nothing launched --
+    for an empty shard or a reduce grid that would not be resident at once.
+    """
+    lib = load()
+    n_steps = len(bounds) - 1
+    if n_steps <= 0:
+        return rows
+    N = branch.shape[0]
+    _dev_f64(branch, 'branch', (N, desc.branch_in))
+    if desc.model == MODEL_QUANONET:
+        _dev_f64(trunk, 'trunk', (N, desc.trunk_in))
+    _dev_f64(y, 'y')
+    for t, nm in ((params, 'params'), (rows, 'rows'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
+        _dev_f64(t, nm)
+    P = params.numel()
+    if y.numel() != N or bounds[-1] > N or len(global_batches) != n_steps:
+        raise QheaError("model_dp_train_steps: row bounds do not match the arrays")
+    if rows.dim() != 2 or rows.shape[0] < n_steps or rows.shape[1] < P + 2 or exp_avg.numel() != P or exp_avg_sq.numel() != P:
+        raise QheaError("model_dp_train_steps: flat vectors have inconsistent lengths")
+    _dev_f64(ham_diag, 'ham_diag', (1 << desc.n_qubits,))
+    biggest = max(bounds[i + 1] - bounds[i] for i in range(n_steps))
+    ws = _model_ws(desc, biggest, branch.device)
+    rb = (ctypes.c_int64 * (n_steps + 1))(*[int(b) for b in bounds])
+    ib = (ctypes.c_double * n_steps)(*[1.0 / float(g) for g in global_batches])
+    arr = (ctypes.c_void_p * world)(*buffers)
+    with torch.cuda.device(branch.device):
+        rc = lib.qhea_model_dp_train_steps(ctypes.byref(desc), n_steps, rb, _ptr(branch), _ptr(trunk), _ptr(y), _ptr(params),
+                                           _ptr(ham_diag), ib, _ptr(rows), int(rows.stride(0)), _ptr(exp_avg),
+                                           _ptr(exp_avg_sq), int(first_step), float(lr), float(beta1), float(beta2),
+                                           float(eps), float(weight_decay), int(rank), int(world), arr, int(dp_values),
+                                           int(first_seq), float(timeout_ms), _ptr(ws), ws.numel(), _stream(branch.device))
+    if rc == -2:
+        raise Unsupported("qhea_model_dp_train_steps: empty shard or reduce grid not resident at once")
+    _check(rc, 'qhea_model_dp_train_steps')
     return rows
 
 

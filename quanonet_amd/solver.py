@@ -122,20 +122,35 @@ class PeerExchange:
 
     @classmethod
     def create(cls, dist, rank, world, n_values, device, log=None):
+        """Returns (exchange or None, reason): the reason says in words which path the data-parallel step takes and why
+        (bench.py prints it as config.dp_exchange_reason; rank 0 logs it)."""
         from . import _lib
         say = log if (log is not None and rank == 0) else (lambda *a, **k: None)
-        if world < 2 or world > _lib.DP_MAX_RANKS or device.type != 'cuda':
-            return None
+
+        def out(px, reason):
+            say("data-parallel exchange: " + reason)
+            return px, reason
+        if world < 2:
+            return None, "single rank: no exchange"
+        if world > _lib.DP_MAX_RANKS or device.type != 'cuda':
+            return out(None, f"all_reduce: world size {world} on {device.type} is outside the peer exchange "
+                             f"(HIP devices, at most {_lib.DP_MAX_RANKS} ranks)")
         if os.environ.get('QHEA_DP_EXCHANGE', 'peer').lower() in ('rccl', 'nccl', 'off', '0'):
-            return None
+            return out(None, "all_reduce: QHEA_DP_EXCHANGE=" + os.environ['QHEA_DP_EXCHANGE'])
+        env = os.environ.get(_lib.IPC_ENV)
+        env_note = ""
+        if env != '0':
+            env_note = f" ({_lib.IPC_ENV}={env!r}: hipIpc handles need the dmabuf mode, value 0)"
+        elif _lib.IPC_ENV_SET_LATE:
+            env_note = f" ({_lib.IPC_ENV}=0 was set after this process had initialised the GPU: export it before launch)"
         self = cls(dist, rank, world, n_values, device)
-        ok = 1
+        ok, why = 1, ""
         handle = None
         try:
             self.own = _lib.dp_alloc(self.n, world, device)
             handle = _lib.dp_export(self.own, device)
-        except _lib.QheaError:
-            ok = 0
+        except _lib.QheaError as e:
+            ok, why = 0, f"rank {rank}: {e}"
         handles = [None] * world
         dist.all_gather_object(handles, handle)
         if ok and all(h is not None for h in handles):
@@ -144,20 +159,20 @@ class PeerExchange:
                 for r in range(world):
                     if r != rank:
                         self.bufs[r] = _lib.dp_import(handles[r], device)
-            except _lib.QheaError:
-                ok = 0
-        else:
-            ok = 0
+            except _lib.QheaError as e:
+                ok, why = 0, f"rank {rank}: {e}"
+        elif ok:
+            ok, why = 0, "a peer could not allocate or export its buffer"
+        whys = [None] * world
+        dist.all_gather_object(whys, why)                      # everybody learns the first failure's text
         if not self._agree(ok):
-            say("data-parallel exchange: peer buffers could not be mapped on every rank -> RCCL all-reduce")
             self.close()
-            return None
+            first = next((w for w in whys if w), "unknown")
+            return out(None, f"all_reduce: peer buffers could not be mapped on every rank [{first}]{env_note}")
         if not self._agree(self._self_check()):
-            say("data-parallel exchange: self-check failed -> RCCL all-reduce")
             self.close()
-            return None
-        say(f"data-parallel exchange: peer-mapped buffers, {world} ranks, {self.n} values")
-        return self
+            return out(None, f"all_reduce: the peer exchange's self-check (three rounds against the analytic sum) failed{env_note}")
+        return out(self, f"peer-mapped buffers over hipIpc, {world} ranks, {self.n} values per rank; self-check passed")
 
     def _agree(self, ok):
         t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=self.device)
@@ -196,6 +211,7 @@ class PeerExchange:
         _lib.dp_status(self.own, self.device)
 
     def close(self):
+        """Collective: every rank calls it (also the ranks whose own allocation failed in create)."""
         from . import _lib
         for r, b in enumerate(self.bufs):
             if b is not None and r != self.rank:
@@ -204,12 +220,9 @@ class PeerExchange:
                 except _lib.QheaError:
                     pass
         self.bufs = [None] * self.world
+        self.dist.barrier()                            # every importer has closed its mapping of the buffers freed next
         if self.own is not None:
-            try:
-                self.dist.barrier()                    # every importer has closed its mapping of the buffer freed next
-                _lib.dp_free(self.own, self.device)
-            except Exception:
-                pass
+            _lib.dp_free(self.own, self.device)
             self.own = None
 
 
@@ -266,10 +279,18 @@ class DataParallelTrainer:
                 kw['fused'] = True
             self.optimizer = cls(self.params, lr=lr, **kw)
         self.peer = None
+        self.peer_fused = False              # the exchange runs inside the reduce kernel (qhea_model_dp_train_steps)
+        self.dp_exchange_reason = "single rank: no exchange"
         if self.world > 1:
             self.broadcast_parameters()
-            if isinstance(self.optimizer, FlatAdam) and peer_exchange:
-                self.peer = PeerExchange.create(dist, dist.get_rank(), self.world, self.numel + 2, p0.device, log=log)
+            if not isinstance(self.optimizer, FlatAdam):
+                self.dp_exchange_reason = "all_reduce: the peer exchange fuses the flat Adam update; this optimizer is torch's"
+            elif not peer_exchange:
+                self.dp_exchange_reason = "all_reduce: requested (peer_exchange=False / config dp_exchange)"
+            else:
+                self.peer, self.dp_exchange_reason = PeerExchange.create(dist, dist.get_rank(), self.world, self.numel + 2,
+                                                                         p0.device, log=log)
+                self.peer_fused = self.peer is not None and self.desc is not None
 
     def broadcast_parameters(self):
         self.dist.broadcast(self.pflat, src=0)
@@ -330,6 +351,19 @@ class DataParallelTrainer:
                                   g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'],
                                   ham_diag=self._ham_diag())
             return flat
+        gb_all = float(global_batch if global_batch is not None else batch[-1].shape[0] * self.world)
+        if self.peer_fused and gb_all >= self.world and batch[-1].shape[0] > 0:
+            # the sum over the ranks inside this step's reduce kernel (qhea_model_dp_train_steps, one step).  Every rank
+            # must take the same path: the choice rests on the GLOBAL batch (contiguous near-even shards, shard_slice,
+            # are all non-empty when it is at least the world size)
+            from . import _lib
+            *inputs, y = batch
+            gb = gb_all
+            try:
+                self._dp_steps(inputs, y, [0, y.shape[0]], [gb], flat.view(1, -1))
+                return flat
+            except _lib.Unsupported:
+                self.peer_fused = False                 # reduce grid not resident at once: separate exchange kernel from now on
         self.loss_and_grad(*batch, global_batch=global_batch, out=out)
         if self.peer is not None:
             # sum over the ranks' peer-mapped buffers + Adam in ONE launch (csrc/hea_dp.hip)
@@ -342,16 +376,39 @@ class DataParallelTrainer:
         self.optimizer.step()
         return flat
 
+    def _dp_steps(self, inputs, y, bounds, global_batches, rows):
+        from . import _lib
+        opt, g, px = self.optimizer, self.optimizer.param_groups[0], self.peer
+        n_steps = len(bounds) - 1
+        _lib.model_dp_train_steps(self.desc, bounds, global_batches, inputs[0], inputs[1] if len(inputs) > 1 else None,
+                                  y.reshape(-1), self.pflat, rows, opt.exp_avg, opt.exp_avg_sq, opt.t + 1, g['lr'],
+                                  g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], px.rank, px.world, px.bufs,
+                                  px.n, px.seq + 1, timeout_ms=px.timeout_ms, ham_diag=self._ham_diag())
+        opt.t += n_steps
+        px.seq += n_steps
+
+    @property
+    def epoch_call(self):
+        """Whether train_steps can issue a run of steps from one host call: the fused single-device path, or the
+        data-parallel path with the exchange inside the reduce kernel."""
+        return self.accepts_out and (self.world == 1 or self.peer_fused)
+
     def train_steps(self, inputs, y, bounds, global_batches, rows):
         """
-        Single device, fused path: the steps of a whole epoch from ONE host call (qhea_model_train_steps) -- step i on rows
-        bounds[i]:bounds[i+1] of the contiguous `inputs` / `y`, its [gradients | sse | sum y^2] left in rows[i].
-        Bitwise the result of calling train_step(..., out=rows[i]) in a loop, without the interpreter between launches.
+        The steps of a whole epoch from ONE host call -- step i on rows bounds[i]:bounds[i+1] of the contiguous `inputs` /
+        `y` (this rank's shards), its [gradients | sse | sum y^2] (summed over the ranks) left in rows[i].  One device:
+        qhea_model_train_steps; several: qhea_model_dp_train_steps, the sum over the ranks inside each step's reduce kernel
+        (raises _lib.Unsupported, nothing launched, if a shard is empty).  Bitwise the result of calling
+        train_step(..., out=rows[i]) in a loop, without the interpreter between launches.
         """
-        assert self.world == 1 and self.accepts_out
+        assert self.epoch_call
         from . import _lib
-        opt, g = self.optimizer, self.optimizer.param_groups[0]
         n_steps = len(bounds) - 1
+        if self.world > 1:
+            self._dp_steps(inputs, y, bounds, global_batches, rows)
+            self._last = rows[n_steps - 1]
+            return rows
+        opt, g = self.optimizer, self.optimizer.param_groups[0]
         _lib.model_train_steps(self.desc, bounds, global_batches, inputs[0], inputs[1] if len(inputs) > 1 else None,
                                y.reshape(-1), self.pflat, rows, opt.exp_avg, opt.exp_avg_sq, opt.t + 1, g['lr'],
                                g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], ham_diag=self._ham_diag())
@@ -367,11 +424,26 @@ class DataParallelTrainer:
     def check_status(self):
         """Raise if a backward kernel reported a hand-off overrun since the last check (qhea_check_status; that call's
         gradients were NaN-poisoned and its Adam update skipped).  Synchronises: call where the host waits anyway."""
-        if self.pflat.is_cuda:
-            from . import _lib
+        if not self.pflat.is_cuda:
+            return
+        from . import _lib
+        err = None
+        try:
             _lib.check_status(self.pflat.device)
             if self.peer is not None:
                 self.peer.check_status()
+        except _lib.QheaError as e:
+            err = e
+        if self.world > 1:
+            # the ranks agree on the outcome BEFORE anybody acts on it (rank 0 saving a checkpoint, ADVICE r2): a failure
+            # on any rank raises on every rank
+            t = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=self.pflat.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            if err is None and t.item() > 0.5:
+                err = _lib.QheaError("a peer rank reported a failed step (pipeline overrun or exchange timeout): "
+                                     "the replicas are no longer in step")
+        if err is not None:
+            raise err
 
 
 class PTSolver:
@@ -517,9 +589,12 @@ class PTSolver:
             rows = (torch.zeros(nb, nm + 2, dtype=torch.float64, device=self.device) if self.trainer.accepts_out
                     else None)
             tails = rows[:, nm:] if rows is not None else torch.zeros(nb, 2, dtype=torch.float64, device=self.device)
-            if rows is not None and self.world == 1 and self.config.get('epoch_call', True):
-                # the whole epoch's inner loop from one host call (no interpreter between the launches;
-                # config['epoch_call'] = False keeps one host call per step)
+            # the whole epoch's inner loop from one host call (no interpreter between the launches; config['epoch_call'] =
+            # False keeps one host call per step).  Several ranks: every rank must take the same path, so the choice rests on
+            # what all of them know -- no global batch smaller than the world size (an empty shard somewhere)
+            one_call = (rows is not None and self.trainer.epoch_call and self.config.get('epoch_call', True) and
+                        min(bs, n - (nb - 1) * bs) >= self.world)
+            if one_call:
                 self.trainer.train_steps(ep_inputs, ep_output, bounds, [min(bs, n - i * bs) for i in range(nb)], rows)
             else:
                 for i in range(nb):

@@ -51,7 +51,7 @@ def worker(rank, world, port, q):
     dev = torch.device('cuda', 0)
     res = {}
     for n in (2403, 5763):
-        px = PeerExchange.create(dist, rank, world, n, dev)
+        px, _reason = PeerExchange.create(dist, rank, world, n, dev)
         g = torch.randn(n, dtype=torch.float64, device=dev)
         p = torch.randn(n - 2, dtype=torch.float64, device=dev); m = torch.zeros_like(p); v = torch.zeros_like(p)
         def ex():

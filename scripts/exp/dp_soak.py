@@ -16,7 +16,7 @@ def worker(rank, world, port, rounds, q):
     from quanonet_amd.solver import PeerExchange
     dev = torch.device('cuda', 0)
     n = 2403
-    px = PeerExchange.create(dist, rank, world, n, dev)
+    px, _reason = PeerExchange.create(dist, rank, world, n, dev)
     assert px is not None
     ramp = torch.arange(n, dtype=torch.float64, device=dev) * 1e-3
     worst = torch.zeros((), dtype=torch.float64, device=dev)

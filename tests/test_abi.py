@@ -144,7 +144,8 @@ def test_module_surface_matches_reference_contract(lib):
 def test_dp_exchange_argument_validation_without_gpu(lib):
     """qhea_dp_*: sizes and argument errors are decided on the host before any HIP call."""
     vp = ctypes.c_void_p
-    assert lib.qhea_dp_buffer_bytes(2403, 8) == 256 + 2 * 8 * 2404 * 8          # header + 2 parities x world x padded values
+    # header + block flags [16 ranks][512 blocks] + 2 parities x world x padded values
+    assert lib.qhea_dp_buffer_bytes(2403, 8) == 256 + 16 * 512 * 8 + 2 * 8 * 2404 * 8
     assert lib.qhea_dp_buffer_bytes(2403, 17) == 0                              # QHEA_DP_MAX_RANKS = 16
     assert lib.qhea_dp_buffer_bytes(0, 2) == 0
     assert lib.qhea_dp_alloc(0, 2, ctypes.byref(vp())) == -1
@@ -182,3 +183,30 @@ def test_train_steps_argument_validation_without_gpu(lib):
     assert call(bad_rows, P + 2, 1) == -1            # an empty step
     assert call(ok_rows, P + 1, 1) == -1             # rows too narrow for [grads | sse | sum y^2]
     assert call(ok_rows, P + 2, 0) == -1             # Adam update count starts at 1
+
+
+def test_dp_train_steps_argument_validation_without_gpu(lib):
+    """qhea_model_dp_train_steps decides everything it can on the host BEFORE the first launch: a rank that stopped half-way
+    through a run of steps would leave its peers waiting."""
+    from quanonet_amd import _lib
+    lib.qhea_model_dp_train_steps.restype = ctypes.c_int
+    desc = _lib.ModelDesc(0, 5, (ctypes.c_int32 * 4)(40, 2, 20, 2), 100, 2, 1, 0, 0.1, 0.0, 1.0)
+    i64, vp = ctypes.c_int64, ctypes.c_void_p
+    fake = vp(8)
+    ok_rows = (i64 * 3)(0, 4, 8); empty_rows = (i64 * 3)(0, 4, 4); bad_rows = (i64 * 3)(0, 4, 2)
+    inv = (ctypes.c_double * 2)(0.25, 0.25)
+    bufs = (vp * 2)(8, 8)
+    P = lib.qhea_model_param_count(ctypes.byref(desc))
+
+    def call(rows=ok_rows, stride=P + 2, first=1, rank=0, world=2, buffers=bufs, dp_values=P + 2, seq=1, timeout=100.0):
+        return lib.qhea_model_dp_train_steps(ctypes.byref(desc), 2, rows, fake, fake, fake, fake, None, inv, fake, i64(stride),
+                                             fake, fake, i64(first), ctypes.c_double(1e-4), ctypes.c_double(0.9),
+                                             ctypes.c_double(0.999), ctypes.c_double(1e-8), ctypes.c_double(0.0), rank, world,
+                                             buffers, i64(dp_values), i64(seq), ctypes.c_double(timeout), None, 0, None)
+    assert call(world=1) == -1 and call(world=17) == -1 and call(rank=2) == -1
+    assert call(seq=0) == -1 and call(timeout=0.0) == -1 and call(first=0) == -1
+    assert call(dp_values=P + 1) == -1 and call(stride=P + 1) == -1
+    assert call(buffers=(vp * 2)(8, None)) == -1
+    assert call(rows=bad_rows) == -1
+    assert call(rows=empty_rows) == -2               # an empty shard: QHEA_EUNSUPPORTED, the caller takes the separate exchange
+    assert call() == -3                              # everything valid up to the (missing) workspace: nothing was launched

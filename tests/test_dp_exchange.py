@@ -6,7 +6,10 @@ just as it maps one on a peer device; what a one-GPU box cannot show is the xGMI
 * raw exchange: sums in rank order, both slot parities, slot reuse over many rounds, in-place operation, Adam fused;
 * the whole PTSolver loop over 2 and 3 ranks through the exchange equals the committed single-process trace
   (tests/golden/ptsolver_trajectory.npz, the independent CPU loop of make_trajectory.py);
-* a rank that never hears from a peer reports QHEA_EEXCHANGE, leaves NaN gradients and does not update.
+* a rank that never hears from a peer reports QHEA_EEXCHANGE, leaves NaN gradients and does not update -- and so does the
+  late rank and every later exchange (a timeout is fatal on every rank);
+* the data-parallel step with the exchange inside the reduce kernel (qhea_model_dp_train_steps) equals the separate
+  exchange bitwise.
 """
 import os
 import socket
@@ -41,8 +44,8 @@ def _raw_worker(rank, world, port, q):
     from quanonet_amd.solver import PeerExchange, FlatAdam
     dev = torch.device('cuda', 0)
     n = 2403
-    px = PeerExchange.create(dist, rank, world, n, dev)
-    assert px is not None, "peer exchange not available"
+    px, reason = PeerExchange.create(dist, rank, world, n, dev)
+    assert px is not None, reason
     rng = np.random.default_rng(100 + rank)
     worst = 0.0
     for rnd in range(40):                                          # many rounds: parities alternate, slots are reused
@@ -135,34 +138,163 @@ def test_multi_rank_ptsolver_through_the_peer_exchange_equals_the_trace(world, e
 
 
 def _timeout_worker(rank, world, port, q):
+    """Rank 1 stays away from exchange 1 until rank 0 has given up on it (50 ms), then issues it: the late rank must fail
+    too and leave its parameters alone (a timeout is fatal on every rank), and so must every later exchange."""
+    import time
     dist = _init(rank, world, port)
     from quanonet_amd import _lib
     from quanonet_amd.solver import PeerExchange
     dev = torch.device('cuda', 0)
     n = 64
-    px = PeerExchange.create(dist, rank, world, n, dev)
-    assert px is not None
-    out = None
-    if rank == 0:                                                  # rank 1 never publishes this round
+    px, reason = PeerExchange.create(dist, rank, world, n, dev)
+    assert px is not None, reason
+
+    def one(timeout_ms):
         local = torch.ones(n, dtype=torch.float64, device=dev)
         p = torch.ones(n - 2, dtype=torch.float64, device=dev)
         m, v = torch.zeros_like(p), torch.zeros_like(p)
         px.seq += 1
-        _lib.dp_allreduce_adam(rank, world, px.bufs, px.seq, local, local, p, m, v, 1, 1e-2, timeout_ms=50.0)
+        _lib.dp_allreduce_adam(rank, world, px.bufs, px.seq, local, local, p, m, v, 1, 1e-2, timeout_ms=timeout_ms)
         try:
             px.check_status()
             raised = None
         except _lib.QheaError as e:
             raised = str(e)
-        out = (bool(torch.isnan(local).all()), bool((p == 1.0).all()), raised)
-    q.put((rank, out))
+        return bool(torch.isnan(local).all()), bool((p == 1.0).all()), raised
+    if rank == 0:
+        first = one(50.0)                                          # rank 1 has not published: overrun
+        dist.barrier()
+    else:
+        dist.barrier()                                             # ... rank 0 has given up by now
+        t0 = time.perf_counter()
+        first = one(5000.0)                                        # the late rank: fails at once, does not wait out its bound
+        assert time.perf_counter() - t0 < 2.0
+    dist.barrier()
+    second = one(5000.0)                                           # sticky: both ranks fail the next exchange at once
+    q.put((rank, first, second))
     dist.barrier()
     px.close()
     dist.destroy_process_group()
 
 
-def test_missing_contribution_is_reported_not_computed_through():
+def test_missing_contribution_is_fatal_on_every_rank():
     res = _spawn(_timeout_worker, 2)
-    nan_out, untouched, raised = res[0][1]
-    assert nan_out and untouched
-    assert raised is not None and '(-7)' in raised
+    for rank, first, second in res:
+        for nan_out, untouched, raised in (first, second):
+            assert nan_out and untouched, (rank, first, second)
+            assert raised is not None and '(-7)' in raised
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the data-parallel step with the exchange INSIDE the reduce kernel (qhea_model_dp_train_steps): bitwise the separate path
+# ------------------------------------------------------------------------------------------------------------------
+def _fused_worker(rank, world, port, q, nq, net, kind, rows_per_step):
+    dist = _init(rank, world, port)
+    from quanonet_amd.models import QuanONetPT, HEAQNNPT
+    from quanonet_amd.solver import DataParallelTrainer, shard_slice
+    dev = torch.device('cuda', 0)
+    steps = len(rows_per_step)
+    rng = np.random.default_rng(5)                                  # the same global data on every rank
+    n_rows = sum(rows_per_step)
+    b_in = 7
+    branch = rng.normal(size=(n_rows, b_in)); trunk = rng.uniform(size=(n_rows, 2)); y = rng.normal(size=(n_rows, 1))
+    # this rank's contiguous shard of every global batch, concatenated (what PTSolver._stage_epoch gathers)
+    sel, bounds, off = [], [0], 0
+    for gb in rows_per_step:
+        lo, hi = shard_slice(gb, rank, world)
+        sel.extend(range(off + lo, off + hi)); bounds.append(bounds[-1] + hi - lo); off += gb
+    t = lambda a: torch.tensor(np.ascontiguousarray(a[sel]), dtype=torch.float64, device=dev)
+    ins = [t(branch), t(trunk)] if kind == 'quanonet' else [t(np.concatenate([branch, trunk], axis=1))]
+    yd = t(y)
+
+    def make(fused):
+        torch.manual_seed(11)
+        if kind == 'quanonet':
+            m = QuanONetPT(nq, b_in, 2, net, scale_coeff=0.1, if_trainable_freq=True).double().to(dev)
+        else:
+            m = HEAQNNPT(nq, b_in + 2, net, scale_coeff=0.1, if_trainable_freq=True).double().to(dev)
+        tr = DataParallelTrainer(m, lr=1e-2, world_size=world, dist=dist)
+        assert tr.peer is not None and tr.peer_fused, tr.dp_exchange_reason
+        tr.peer_fused = fused
+        return tr
+    a, b = make(False), make(True)
+    rows_a = torch.zeros(steps, a.numel + 2, dtype=torch.float64, device=dev)
+    rows_b = torch.zeros_like(rows_a)
+    for i in range(steps):                                          # separate path: loss_grad launches + one exchange kernel
+        lo, hi = bounds[i], bounds[i + 1]
+        a.train_step(*[x[lo:hi] for x in ins], yd[lo:hi], global_batch=rows_per_step[i], out=rows_a[i])
+    b.train_steps(ins, yd, bounds, rows_per_step, rows_b)          # exchange inside the reduce kernels, one host call
+    torch.cuda.synchronize()
+    a.check_status(); b.check_status()
+    same_rows = bool(torch.equal(rows_a, rows_b))
+    same_p = bool(torch.equal(a.pflat, b.pflat)) and bool(torch.equal(a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq))
+    # one more single step through train_step on both (b: qhea_model_dp_train_steps with one step)
+    lo, hi = bounds[0], bounds[1]
+    fa = a.train_step(*[x[lo:hi] for x in ins], yd[lo:hi], global_batch=rows_per_step[0]).clone()
+    fb = b.train_step(*[x[lo:hi] for x in ins], yd[lo:hi], global_batch=rows_per_step[0]).clone()
+    torch.cuda.synchronize()
+    same_single = bool(torch.equal(fa, fb)) and bool(torch.equal(a.pflat, b.pflat))
+    q.put((rank, same_rows, same_p, same_single, b.peer_fused, b.pflat.cpu().numpy(), rows_b.cpu().numpy()))
+    dist.barrier()
+    a.peer.close(); b.peer.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,nq,net,kind,rows_per_step', [
+    (2, 5, (3, 2, 2, 2), 'quanonet', [64, 64, 64, 37]),      # block-unrolled shape: steps 2, 3 take their records from the previous reduce
+    (3, 5, (3, 2, 2, 2), 'quanonet', [64, 64, 64, 37]),      # uneven shards (64 = 22 + 21 + 21)
+    (2, 4, (3, 2, 2, 1), 'quanonet', [50, 50, 31]),          # mixed sub-layer counts: generic walk, a prep launch per step
+    (2, 2, (4, 2, 3, 2), 'quanonet', [32, 32, 32]),          # n = 2
+    (2, 8, (2, 2), 'heaqnn', [40, 40, 24]),                  # first-generation kernels (n = 8), no bias
+    (2, 10, (2, 1, 1, 1), 'quanonet', [12, 12]),             # workgroup-resident kernels (n = 10)
+    (2, 5, (2, 2, 2, 2), 'quanonet', [4608, 4608, 1000]),    # one-wave ZYZ kernel (2304 rows per rank)
+])
+def test_exchange_inside_the_reduce_kernel_equals_the_separate_exchange_bitwise(world, nq, net, kind, rows_per_step):
+    res = _spawn(_fused_worker, world, extra=(nq, net, kind, rows_per_step))
+    for rank, same_rows, same_p, same_single, still_fused, p, rows in res:
+        assert still_fused, "the fused data-parallel step fell back to the separate exchange"
+        assert same_rows and same_p and same_single, (rank, same_rows, same_p, same_single)
+        np.testing.assert_array_equal(p, res[0][5])                  # replicas bitwise identical
+        np.testing.assert_array_equal(rows, res[0][6])               # every rank holds the same global rows
+        assert np.isfinite(rows).all() and (rows[:, -2] > 0).all()
+
+
+def _fused_timeout_worker(rank, world, port, q):
+    """The fused step with a missing peer: every block of rank 0's reduce kernel gives up, nothing is updated, the late rank
+    fails as well."""
+    dist = _init(rank, world, port)
+    from quanonet_amd import _lib
+    from quanonet_amd.models import QuanONetPT
+    from quanonet_amd.solver import DataParallelTrainer
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(3)
+    tr = DataParallelTrainer(QuanONetPT(5, 7, 2, (3, 2, 2, 2), scale_coeff=0.1, if_trainable_freq=True).double().to(dev),
+                             lr=1e-2, world_size=world, dist=dist)
+    assert tr.peer_fused, tr.dp_exchange_reason
+    rng = np.random.default_rng(rank)
+    br = torch.tensor(rng.normal(size=(20, 7)), device=dev); tk = torch.tensor(rng.uniform(size=(20, 2)), device=dev)
+    y = torch.tensor(rng.normal(size=(20, 1)), device=dev)
+    before = tr.pflat.clone()
+    tr.peer.timeout_ms = 50.0 if rank == 0 else 5000.0
+    if rank == 1:
+        dist.barrier()
+    flat = tr.train_step(br, tk, y, global_batch=40).clone()
+    torch.cuda.synchronize()
+    if rank == 0:
+        dist.barrier()
+    try:
+        tr.check_status()                                           # collective: agrees on the outcome across the ranks
+        raised = None
+    except _lib.QheaError as e:
+        raised = str(e)
+    q.put((rank, bool(torch.isnan(flat).all()), bool(torch.equal(before, tr.pflat)), raised))
+    dist.barrier()
+    tr.peer.close()
+    dist.destroy_process_group()
+
+
+def test_fused_step_with_a_missing_peer_fails_on_every_rank():
+    res = _spawn(_fused_timeout_worker, 2)
+    for rank, all_nan, untouched, raised in res:
+        assert all_nan and untouched, (rank, all_nan, untouched)
+        assert raised is not None and ('(-7)' in raised or 'peer rank' in raised)
