@@ -237,6 +237,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the other BASELINE configs (N = 1 only)')
+    ap.add_argument('--budget-scale', type=float, default=1.0, help='scales the seconds of repeated windows per measurement')
     ap.add_argument('--backend', default='nccl', help='collective backend; "gloo" + --same-device rehearses N>1 on one GPU')
     ap.add_argument('--same-device', action='store_true', help='rehearsal only: every rank uses cuda:0')
     ap.add_argument('--batch', type=int, default=BATCH, help='samples per GPU and step (the headline is 1024)')
@@ -290,7 +291,7 @@ def main():
     # One device: the steps are issued as the product's epoch loop issues them (PTSolver.train -> qhea_model_train_steps):
     # runs of consecutive steps from one host call, inside which a step's reduce kernel writes the next step's layer
     # records instead of a prep launch.  Same batches in the same order as the per-step loop (step i: batch i mod 8).
-    epoch_call = world == 1 and trainer.accepts_out and not os.environ.get('QHEA_BENCH_PER_STEP')
+    epoch_call = trainer.epoch_call and not os.environ.get('QHEA_BENCH_PER_STEP')
     rows = torch.zeros(n_batches, trainer.numel + 2, dtype=torch.float64, device=dev) if epoch_call else None
     bounds = [j * batch for j in range(n_batches + 1)]
 
@@ -335,10 +336,18 @@ def main():
         clock ramp after the idle fence to move it by several percent (BASELINE.md section 3 asks for the median).  The
         budgets add up to > 3 s of GPU work per run, so that a sampler outside the process sees the device busy."""
         w0 = timed_window(fn, k, 0)
-        n_win = int(min(1000, max(5, np.ceil(budget_s / max(w0, 1e-6)))))
+        n_win = int(min(1000, max(5, np.ceil(args.budget_scale * budget_s / max(w0, 1e-6)))))
         wins = [w0] + [timed_window(fn, k, (j + 1) * k) for j in range(n_win - 1)]
         return float(np.median(wins)), wins
 
+    if world > 1 and not os.environ.get('QHEA_BENCH_NO_CALIBRATION'):
+        # as PTSolver.train does before its first epoch: both forms of the peer exchange timed on one batch, the faster kept
+        trainer.calibrate_exchange(branch[:batch], trunk[:batch], y[:batch], global_batch=batch * world)
+        epoch_call = trainer.epoch_call and not os.environ.get('QHEA_BENCH_PER_STEP')
+        if rank == 0:
+            print("data-parallel exchange: " + trainer.dp_exchange_reason, file=sys.stderr, flush=True)
+        if not epoch_call and hasattr(step, 'many'):
+            del step.many
     if epoch_call:
         run_steps(0, args.warmup)
     else:
@@ -347,6 +356,41 @@ def main():
     elapsed, windows = measure(step, args.steps)
     samples_per_s = batch * world * args.steps / elapsed
     trainer.check_status()
+
+    # N > 1: which devices the ranks ran on, and the same step through the OTHER exchanges in the same run (every rank
+    # switches together), so that the line explains itself: the exchange inside the reduce kernel (the headline when the
+    # peer buffers could be mapped), the separate one-workgroup exchange kernel, and the collective library's all-reduce
+    devices, alternatives = None, None
+    if world > 1:
+        pr = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev.index, "name": pr.name,
+                "pci_bus_id": getattr(pr, 'pci_bus_id', None), "pci_device_id": getattr(pr, 'pci_device_id', None),
+                "pci_domain_id": getattr(pr, 'pci_domain_id', None), "uuid": str(getattr(pr, 'uuid', '')),
+                "compute_units": pr.multi_processor_count, "hostname": os.uname().nodename, "pid": os.getpid()}
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
+        per_step = lambda i: step(i)                                   # no .many: one host call per step
+        alternatives = {"headline (the product's calibrated choice): " +
+                        ("exchange inside the reduce kernel, runs of steps per host call" if epoch_call else
+                         "one host call per step"): 1e3 * elapsed / args.steps}
+        saved = (trainer.peer, trainer.peer_fused)
+        if trainer.peer is not None:
+            if trainer.desc is not None and trainer.fused_ok:
+                trainer.peer_fused = True
+                el, _ = measure(per_step, args.steps, budget_s=0.5)
+                alternatives["exchange inside the reduce kernel, one host call per step"] = 1e3 * el / args.steps
+                if trainer.peer_fused and not saved[1]:
+                    run_steps.many = run_steps
+                    el, _ = measure(run_steps, args.steps, budget_s=0.5)
+                    alternatives["exchange inside the reduce kernel, runs of steps per host call"] = 1e3 * el / args.steps
+            trainer.peer_fused = False
+            el, _ = measure(per_step, args.steps, budget_s=0.5)
+            alternatives["separate one-workgroup exchange kernel (prep, circuit, reduce, exchange + Adam)"] = 1e3 * el / args.steps
+        trainer.peer, trainer.peer_fused = None, False
+        el, _ = measure(per_step, args.steps, budget_s=0.5)
+        alternatives[f"all_reduce ({args.backend}) + Adam launch"] = 1e3 * el / args.steps
+        trainer.peer, trainer.peer_fused = saved
+        trainer.check_status()
 
     # forward-only circuit evaluations/s (evaluation path): the resident set in chunks of one batch, issued as
     # PTSolver.predict issues an evaluation (qhea_model_forward_chunks: the layer records are prepared once per call, the
@@ -419,15 +463,22 @@ def main():
                                    "fp64, Adam lr=1e-4, trainable frequency",
                        "global_batch": batch * world, "parallelism": f"dp{world}",
                        "dp_exchange": (None if world == 1 else
-                                       "peer-mapped buffers, sum + Adam in one kernel (csrc/hea_dp.hip)"
-                                       if trainer.peer is not None else "all_reduce (" + args.backend + ") + Adam launch")},
+                                       "peer-mapped buffers, sum over the ranks + Adam inside the reduce kernel "
+                                       "(qhea_model_dp_train_steps: two launches per step)" if trainer.peer_fused else
+                                       "peer-mapped buffers, sum + Adam in one exchange kernel (csrc/hea_dp.hip)"
+                                       if trainer.peer is not None else "all_reduce (" + args.backend + ") + Adam launch"),
+                       "dp_exchange_reason": trainer.dp_exchange_reason,
+                       "world_size": world, "backend": None if world == 1 else args.backend,
+                       "same_device_rehearsal": bool(args.same_device), "devices": devices,
+                       "ms_per_step_by_exchange": alternatives},
             "timing": {"windows": len(windows), "steps_per_window": args.steps,
                        "ms_per_step_median": 1e3 * elapsed / args.steps,
                        "ms_per_step_first_window": 1e3 * windows[0] / args.steps,
                        "ms_per_step_min": 1e3 * min(windows) / args.steps,
                        "ms_per_step_max": 1e3 * max(windows) / args.steps,
-                       "issue": ("runs of up to 8 consecutive steps per host call (qhea_model_train_steps, the epoch loop of "
-                                 "PTSolver.train: a step's reduce kernel writes the next step's layer records)"
+                       "issue": ("runs of up to 8 consecutive steps per host call (qhea_model_train_steps / "
+                                 "qhea_model_dp_train_steps, the epoch loop of PTSolver.train: a step's reduce kernel writes "
+                                 "the next step's layer records)"
                                  if epoch_call else "one host call per step (prep, circuit, reduce launches each)"),
                        "note": "value = median over windows of EXACTLY `steps` training steps each, every window "
                                "bracketed by barrier + device synchronize, max over ranks per window"},

@@ -280,6 +280,7 @@ class DataParallelTrainer:
             self.optimizer = cls(self.params, lr=lr, **kw)
         self.peer = None
         self.peer_fused = False              # the exchange runs inside the reduce kernel (qhea_model_dp_train_steps)
+        self.fused_ok = True                 # ... and has not been found to stall on this placement of ranks (calibrate_exchange)
         self.dp_exchange_reason = "single rank: no exchange"
         if self.world > 1:
             self.broadcast_parameters()
@@ -386,6 +387,71 @@ class DataParallelTrainer:
                                   px.n, px.seq + 1, timeout_ms=px.timeout_ms, ham_diag=self._ham_diag())
         opt.t += n_steps
         px.seq += n_steps
+
+    def calibrate_exchange(self, *batch, global_batch=None, steps=10):
+        """
+        Several ranks, peer buffers mapped: time this very step through both forms of the peer exchange -- inside the
+        reduce kernel (two launches per step) and as a separate one-workgroup kernel (four) -- and keep the faster one.
+        Which one wins depends on where the ranks run: the reduce kernel's waiting blocks hold compute units, which costs
+        nothing when every rank has a GPU of its own and a lot when ranks share one (a rehearsal).  Collective; parameters,
+        Adam state and step count are restored afterwards, so a run is the same with or without the calibration.  Returns
+        (ms per step fused, ms per step separate) or None when there is nothing to choose.
+        """
+        if not self.peer_fused or self.world < 2:
+            return None
+        import time
+        gb = float(global_batch if global_batch is not None else batch[-1].shape[0] * self.world)
+        if gb < self.world or batch[-1].shape[0] == 0:
+            return None
+        from . import _lib
+        opt = self.optimizer
+        keep = (self.pflat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.t)
+        dev = self.pflat.device
+
+        def restore():
+            self.pflat.copy_(keep[0]); opt.exp_avg.copy_(keep[1]); opt.exp_avg_sq.copy_(keep[2]); opt.t = keep[3]
+
+        def timed(fused):
+            self.peer_fused = fused
+            for _ in range(2):                                   # the first pass warms up
+                self.dist.barrier(); torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    self.train_step(*batch, global_batch=global_batch)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+            bad = 0.0
+            try:
+                self.peer.check_status()
+            except _lib.QheaError:
+                bad = 1.0
+            t = torch.tensor([dt, bad], dtype=torch.float64, device=dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return 1e3 * float(t[0].item()) / steps, bool(t[1].item() > 0.5)
+        # The trial inside the reduce kernel runs with a short bound: where ranks SHARE a GPU its waiting blocks can keep a
+        # peer's kernels off the compute units for good (seen with three ranks on one device).  A failed trial has poisoned
+        # the buffers (a timeout is fatal by design): they are re-created and the separate kernel is kept.
+        long_timeout, self.peer.timeout_ms = self.peer.timeout_ms, 250.0
+        t_fused, failed = timed(True)
+        self.peer.timeout_ms = long_timeout
+        if failed:
+            restore()
+            torch.cuda.synchronize(dev)
+            self.peer.close()
+            self.peer, why = PeerExchange.create(self.dist, self.dist.get_rank(), self.world, self.numel + 2, dev)
+            self.peer_fused = False
+            self.fused_ok = False
+            self.dp_exchange_reason = (why + "; calibrated on this step: the exchange inside the reduce kernel did not complete "
+                                       "within 250 ms (ranks sharing a GPU?) -> separate kernel, buffers re-created")
+            return None
+        t_sep, failed = timed(False)
+        restore()
+        if failed:
+            raise _lib.QheaError("data-parallel exchange failed during calibration")
+        self.peer_fused = t_fused <= t_sep                      # (the same numbers on every rank: one decision)
+        self.dp_exchange_reason += (f"; calibrated on this step: {t_fused:.4f} ms inside the reduce kernel, {t_sep:.4f} ms "
+                                    f"as a separate kernel -> " + ("inside the reduce kernel" if self.peer_fused else "separate kernel"))
+        return t_fused, t_sep
 
     @property
     def epoch_call(self):
@@ -580,6 +646,12 @@ class PTSolver:
         os.makedirs(self.out_dir, exist_ok=True)
         self.best_model_path = os.path.join(self.out_dir, 'best_model.pt')
         staged = self._stage_epoch(n, bs, nb) if epochs > 0 else None
+        if staged is not None and self.world > 1 and self.config.get('dp_calibrate', True):
+            # both forms of the peer exchange timed on the first batch, the faster one kept (state restored afterwards)
+            _, b0, in0, out0 = staged
+            r = self.trainer.calibrate_exchange(*[t[b0[0]:b0[1]] for t in in0], out0[b0[0]:b0[1]], global_batch=min(bs, n))
+            if r is not None:
+                self.log("data-parallel exchange: " + self.trainer.dp_exchange_reason)
         for epoch in range(epochs):
             self.model.train()
             idx_dev, bounds, ep_inputs, ep_output = staged
