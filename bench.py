@@ -22,6 +22,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import quanonet_amd._lib          # noqa: E402,F401  (first: it sets the IPC mode default before anything initialises the GPU)
 
 N_QUBITS, NET, B_IN, T_IN, BATCH = 5, (40, 2, 20, 2), 100, 2, 1024
 
