@@ -89,6 +89,9 @@ int qhea_device_count(void);
 #define QHEA_BWD_ZTRI2  6      /* ZTRI with two sample groups per workgroup whose gradient sums are added in LDS: half */
                                /* the partial rows.  AUTO does that only where it costs nothing (batches that fill     */
                                /* every CU's two slots); ZTRI2 forces it from one group per CU on, ZTRI never does it   */
+#define QHEA_BWD_ZQUAD  7      /* n = 5, block-unrolled shapes: the pipeline with BOTH sweeps of every chain in the split layout */
+                               /* (one sample per chain wave, four chain waves per sample group).  AUTO runs it while every    */
+                               /* CU holds at most one sample group; ZQUAD forces it at any batch                               */
 int qhea_set_backward_variant(int variant);
 
 /*

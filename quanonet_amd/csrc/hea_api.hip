@@ -181,6 +181,10 @@ __device__ __forceinline__ void prep_layer_body(const Runs& runs, int n, int L, 
                     const double cb = zb.x, sb = -zb.y, ct = g.c * g.c - g.s * g.s, st = 2.0 * g.c * g.s;
                     double* em = reinterpret_cast<double*>(rec + (long)(l - 1) * kRecBytes + kRecRy) + 3 * q;
                     em[0] = cb * ct; em[1] = sb; em[2] = -cb * st;
+                    if (srec) {     // ... and in its split record, for the chains that walk back in the split layout (bwd_zquad_kernel)
+                        double* es = reinterpret_cast<double*>(srec + (long)(l - 1) * kRecBytes + kSRecRy) + 3 * q;
+                        es[0] = cb * ct; es[1] = sb; es[2] = -cb * st;
+                    }
                 }
             }
         }
@@ -421,6 +425,8 @@ struct Layout {
     bool zsplit;            // n = 5, block-unrolled shape, table fits: split records exist (forward sweeps in the split layout)
     bool zfwd_split;        // ... and the forward kernel is the split one (batches that leave SIMDs free; Z / diagonal read-out)
     int zpipes;             // bwd_ztri_kernel: sample groups per workgroup (2 halves the partial rows; hea_zyz.hpp)
+    bool zquad;             // quad-chain pipeline (bwd_zquad_kernel): reverse walks in the split layout too; batches of at most one
+                            // sample group per CU (Z / diagonal read-out: checked at the launch)
 };
 
 // Pipelined backward kernels (n <= 5): several waves per sample group (psi chain, lambda chain, sigma waves), so they
@@ -452,7 +458,7 @@ bool use_pair(int n, int64_t B) {
     if (n > 5 || B <= 0) return false;
     const int v = g_bwd_variant.load(std::memory_order_relaxed);
     if (v == QHEA_BWD_PACKED || v == QHEA_BWD_ZPACKED) return false;
-    if (v == QHEA_BWD_PAIR || v == QHEA_BWD_TRI || v == QHEA_BWD_ZTRI || v == QHEA_BWD_ZTRI2) return true;
+    if (v == QHEA_BWD_PAIR || v == QHEA_BWD_TRI || v == QHEA_BWD_ZTRI || v == QHEA_BWD_ZTRI2 || v == QHEA_BWD_ZQUAD) return true;
     // measured at n = 5 (us per backward call incl. prep/reduce; packed / pipelined): B = 1024 194 / 155, B = 1536
     // 247 / 181, B = 2048 260 / 273 -- pipelined while the sample groups fill at most 3/4 of the SIMDs
     const int spw = 64 >> lane_bits(n);
@@ -483,7 +489,8 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     // variants stay selectable (qhea_set_backward_variant) and take over for shapes whose (cos, sin) table exceeds LDS
     const int var = g_bwd_variant.load(std::memory_order_relaxed);
     const bool zok = zyz_eligible(n, sh.E) &&
-                     (var == QHEA_BWD_AUTO || var == QHEA_BWD_ZTRI || var == QHEA_BWD_ZTRI2 || var == QHEA_BWD_ZPACKED);
+                     (var == QHEA_BWD_AUTO || var == QHEA_BWD_ZTRI || var == QHEA_BWD_ZTRI2 || var == QHEA_BWD_ZPACKED ||
+                      var == QHEA_BWD_ZQUAD);
     // Measured at cfg 2's circuit (us per call incl. prep / reduce; first-generation / ZYZ form):
     //   forward   B = 1024 55 / 44,  4096 87 / 89,  16384 236 / 255 with a record ring per wave (22 KB of LDS per wave
     //             cap the waves per CU once the batch could fill them) -> one ring per workgroup beyond one wave per SIMD
@@ -495,7 +502,7 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     // forward: private-ring kernel while the sweeps leave SIMDs free, shared-ring kernel (block-unrolled shapes) beyond;
     // other shapes fall back to the first-generation forward once two waves per SIMD are reached
     L.zfwd_shared = fast && (var == QHEA_BWD_ZPACKED || (var == QHEA_BWD_AUTO && L.nwaves_fwd > (long)simd_count()));
-    L.zfwd = zok && (L.zfwd_shared || var == QHEA_BWD_ZTRI || var == QHEA_BWD_ZTRI2 || L.nwaves_fwd <= 2L * simd_count());
+    L.zfwd = zok && (L.zfwd_shared || var == QHEA_BWD_ZTRI || var == QHEA_BWD_ZTRI2 || var == QHEA_BWD_ZQUAD || L.nwaves_fwd <= 2L * simd_count());
     L.ztri = zok && L.pair;
     // batches that fill the SIMDs: the one-wave ZYZ kernel for the block-unrolled shapes (B = 16384 at cfg 2's circuit:
     // see DESIGN.md section 3.5), the first-generation packed kernel otherwise
@@ -523,6 +530,11 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
                            (size_t)sh.blk * padded_3n(n) * sizeof(double);
         if (lds <= 158 * 1024) { L.zpipes = 2; L.nwaves = (L.nwaves + 1) / 2; }      // one partial row per workgroup
     }
+    // Quad-chain pipeline: where every CU holds at most one sample group the step time is the length of the dependent chain,
+    // and the split-layout reverse walk shortens it (cfg 2's circuit, us per training step, all-lane / split reverse walk:
+    // DESIGN.md section 3.3a).  Same partial-row layout as the one-pipeline kernel.
+    L.zquad = L.ztri && L.zsplit && L.zpipes == 1 &&
+              (var == QHEA_BWD_ZQUAD || (var == QHEA_BWD_AUTO && L.nwaves <= cus));
     size_t p = kHeaderBytes;                         // WorkspaceHeader
     L.off_U = p;    p = align_up(p + (size_t)(sh.blk + 2) * n * kGateBytes);
     L.off_cs = p;   p = align_up(p + (size_t)B * sh.E * sizeof(double2));
@@ -608,6 +620,10 @@ int launch_zyz_backward(int n, const Shape& sh, int64_t B, const Layout& L, char
 #undef QHEA_CASE
             default: return QHEA_EUNSUPPORTED;
         }
+        return QHEA_OK;
+    }
+    if (L.zquad && n == 5 && pauli == QHEA_PAULI_Z && za.srec) {
+        launch_bwd_zquad_5(dim3((unsigned)L.nwaves), zquad_fixed_lds(kPairRing) + 2 * dyn, st, za);
         return QHEA_OK;
     }
     const size_t dyn_tri = (size_t)L.zpipes * (ztri_fixed_lds(L.zpipes == 2 ? kZRingDepth<2> : kZRingDepth<1>) + (za.srec ? 2 * dyn : dyn)) +
@@ -970,7 +986,7 @@ int qhea_profile_next_circuit_kernel(void* start_event, void* stop_event) {
 }
 
 int qhea_set_backward_variant(int variant) {
-    if (variant < QHEA_BWD_AUTO || variant > QHEA_BWD_ZTRI2) return QHEA_EINVAL;
+    if (variant < QHEA_BWD_AUTO || variant > QHEA_BWD_ZQUAD) return QHEA_EINVAL;
     g_bwd_variant.store(variant, std::memory_order_relaxed);
     return QHEA_OK;
 }

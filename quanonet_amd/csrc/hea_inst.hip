@@ -62,6 +62,10 @@ void QHEA_CAT(launch_bwd_zpacked_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_
 void launch_fwd_split_5(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArgs& a) {
     hipLaunchKernelGGL(fwd_split_kernel<5>, grid, dim3((kSplitWaves + kSplitHelpers) * 64), dyn_lds, st, a);
 }
+void launch_bwd_zquad_5(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a) {
+    // three sigma waves: with two they bound the reverse phase (87 us per cfg-2 step at B = 512 against 77), a fourth changes nothing
+    hipLaunchKernelGGL((bwd_zquad_kernel<kPairRing, kZSigma>), grid, dim3(64 * (4 + kZSigma)), dyn_lds, st, a);
+}
 #endif
 #elif QHEA_N <= 5      // layout-experiment build: the ZYZ kernels need the all-lane layout and are never selected
 void QHEA_CAT(launch_fwd_zyz_, QHEA_N)(dim3, size_t, hipStream_t, const ZFwdArgs&) {}
@@ -70,6 +74,7 @@ void QHEA_CAT(launch_bwd_zpacked_, QHEA_N)(dim3, size_t, hipStream_t, const ZBwd
 void QHEA_CAT(launch_fwd_zshared_, QHEA_N)(dim3, size_t, hipStream_t, const ZFwdArgs&) {}
 #if QHEA_N == 5
 void launch_fwd_split_5(dim3, size_t, hipStream_t, const ZFwdArgs&) {}
+void launch_bwd_zquad_5(dim3, size_t, hipStream_t, const ZBwdArgs&) {}
 #endif
 #endif
 

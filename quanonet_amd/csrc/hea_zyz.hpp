@@ -844,7 +844,12 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
     double2 (*ring)[64] = role == 0 ? psi_ring : lam_ring;
     int* prod = role == 0 ? &sync->psi_prod : &sync->lam_prod;
     int step = 0;
-    auto publish = [&]() {
+    // A publication is two stores: the state, then the step counter the sigma waves poll, ordered by handoff_release()
+    // (s_waitcnt lgkmcnt(0): the state's store has been executed).  Issued back to back the wait stalls the chain for the
+    // store's whole LDS round trip; the block-unrolled walks therefore store the state at the publication point, go on with
+    // the layer's gates (registers only) and raise the counter AFTER them, when the store has long completed and the wait
+    // costs nothing.  The sigma waves see a step ~a layer later, which is off the critical path.
+    auto publish_data = [&]() {
         if (step >= RING) {
 #pragma unroll
             for (int w = 0; w < kZSigma; ++w)
@@ -852,9 +857,12 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
         }
         ring[step & (RING - 1)][lane] = make_double2(sr[0], si[0]);
         ++step;
+    };
+    auto publish_flag = [&]() {
         handoff_release();                                   // hea_device.hpp: data before counter, s_waitcnt lgkmcnt(0)
         __hip_atomic_store(prod, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
+    auto publish = [&]() { publish_data(); publish_flag(); };
 
     if constexpr (MODE != 0) {
         // ---- block-unrolled reverse walk: per block  ring^-1 publish RY(b,LD)^-1 [dg(b,LD)]^-1 ... [dg(b,1)]^-1 publish RX(b)^-1 [dg(b,0)]^-1
@@ -898,17 +906,19 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
             undo_ry(ct);
             bs.template ahead_rel<-(kBDist + 1)>(sl, bl);     // in the gather's shadow
             __builtin_amdgcn_sched_barrier(0);
-            publish();
+            publish_data();
             static_rfor<0, N>([&](auto q) { apply_ry<decltype(q)::value, true>(sr[0], si[0], ct.g[decltype(q)::value]); });
             __builtin_amdgcn_sched_barrier(0);
+            publish_flag();
             if constexpr (LD == 2) {
                 read_chunk(cur, cs_b - kb * (N * CW));
                 apply_phase<true>(sr[0], si[0], ct.dg);
                 undo_ry(cm);
                 __builtin_amdgcn_sched_barrier(0);
-                publish();
+                publish_data();
                 static_rfor<0, N>([&](auto q) { apply_ry<decltype(q)::value, true>(sr[0], si[0], cm.g[decltype(q)::value]); });
                 __builtin_amdgcn_sched_barrier(0);
+                publish_flag();
                 apply_phase<true>(sr[0], si[0], cm.dg);
             } else {
                 apply_phase<true>(sr[0], si[0], ct.dg);
@@ -1234,6 +1244,289 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
 }
 
 // ---------------------------------------------------------------------------------------
+// Quad-chain pipeline (n = 5, block-unrolled shapes, Z / diagonal read-out): the pipelined backward kernel for batches that
+// leave whole CUs' worth of SIMDs free (at most one sample group per CU: B <= 512 on 256 CUs -- cfg 3's per-GPU shard, the
+// reference's own training batch of 100).  There a chain wave is alone on its SIMD and the step time is the length of the
+// dependent chain, so the chains are shortened the way the forward sweeps were: EVERY chain runs in the split layout
+// (lane = k + 32 p, one double per lane, one sample per wave: an RY gate is 2 moves + 2 fp64 instead of 4 + 4), the
+// REVERSE walks too, which takes two chain waves per state where the all-lane walk has one:
+//     wave 0, 1   psi chains of the group's two samples: forward sweep, then psi walked back, published per sub-layer
+//     wave 2, 3   lambda chains of the two samples: lambda_N = g H psi_N, walked back, published likewise
+//     wave 4..    sigma waves, unchanged: they read the hand-off rings in the all-lane order (lane = k + 32 sample), which
+//                 is how the chains store their halves of a slot (8-byte stores at [sample][k].{re, im}).
+// The published states are those of the all-lane walk (the split records differ from the all-lane ones only by fixed phases
+// between an RX chunk's gates and the next diagonal, never at a publication point), so the sums, the chunk-gradient axes and
+// the reduce kernel's gradient map are unchanged and the partial rows have the layout of bwd_ztri_kernel<N, 1>.
+// Daggered split gates: RY(theta)^-1 flips the sign of the partner's coefficient (wire 4's swap form: x' = +-(u.x A - u.y B),
+// - for the lanes with bit 4 set); a diagonal's inverse reads the other two of its record's three entries [-sin, cos, sin].
+// ---------------------------------------------------------------------------------------
+struct ZQSync { int psi_prod[2], lam_prod[2], ready[2], abort; int cursor[4]; int next; };
+__host__ __device__ constexpr size_t zquad_fixed_lds(int ring) {
+    return 4 * (size_t)kBlockRingBytes + 2 * (size_t)ring * 1024 + 1024 + 256 + (size_t)kAxisRing * 15 * sizeof(double);
+}
+__device__ __forceinline__ void split_phase_dag(double& x, const double2& d /* p = 0: (cos, sin); p = 1: (-sin, cos) */) {
+    double A, B;
+    swap_dup<true>(x, A, B);
+    x = d.x * A + d.y * B;
+}
+template <int Q>
+__device__ __forceinline__ void split_ry_dag(double& x, const double2& u, unsigned mask4) {
+    if constexpr (Q == 4) {
+        double A, B;
+        swap_dup<false>(x, A, B);
+        x = flip_sign(u.x * A - u.y * B, mask4);
+    } else {
+        const double own = u.x * x;
+        x = fma(-u.y, xchg<(1 << Q)>(x), own);
+    }
+}
+
+// The sigma waves' walk over a block-unrolled shape (one full RX chunk + LD sub-layers per block), shared by the kernels whose
+// chains run in the split layout: steps drawn from a counter, the RX-chunk gradients read off the block's first sub-layer's
+// products through the batch-invariant axes (see bwd_ztri_kernel, which has the same walk inline).  `prod`: NPROD consecutive
+// producer counters, all of which must have reached a step before its slot is read.
+template <int RING, int NPROD>
+__device__ __forceinline__ void zsigma_walk(const ZBwdArgs& a, int lane, int me, long wave, double2 (*psi_ring)[64], double2 (*lam_ring)[64],
+                                            const double* axis_ring, int* prod, int* abort_flag, int* cursor, int* next) {
+    constexpr int N = 5;
+    using C = Cfg<N>;
+    const int E = a.E;
+    double* __restrict__ part_w = a.partial + wave * (long)a.blk * C::KW;
+    int seen_c[NPROD];
+#pragma unroll
+    for (int i = 0; i < NPROD; ++i) seen_c[i] = 0;
+    auto products = [&](double (&acc3)[C::KW], const double2& pv, const double2 (&qv)[N], const double2& lm) {
+#pragma unroll
+        for (int i = 0; i < C::KW; ++i) acc3[i] = 0.0;
+        static_for<0, N>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            const unsigned m = lane_sign_mask<Q>(lane);
+            acc3[3 * Q] = lm.x * qv[Q].y - lm.y * qv[Q].x;
+            acc3[3 * Q + 1] = flip_sign(-(lm.x * qv[Q].x) - lm.y * qv[Q].y, m);
+            acc3[3 * Q + 2] = flip_sign(lm.x * pv.y - lm.y * pv.x, m);
+        });
+    };
+    auto store_sums = [&](double (&acc3)[C::KW], int sub) {
+        const int vi = butterfly_sum<C::KW>(acc3, lane);
+        if (butterfly_owner<C::KW>(lane)) part_w[(long)sub * C::KW + vi] = acc3[0];
+    };
+    const int LDr = a.fast_ld, nsteps = a.nblocks * LDr;
+    auto draw = [&]() {
+        int v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return v;
+    };
+    int mine = __builtin_amdgcn_readfirstlane(draw());
+    __hip_atomic_store(&cursor[me], mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int after_v = draw();
+    auto sigma_step = [&](auto chunk_c) {
+        constexpr bool CHUNK = decltype(chunk_c)::value;
+        const int t = mine;
+        const int j = LDr == 2 ? (t >> 1) : t;
+        const int sub = a.blk - 1 - t, bl = a.nblocks - 1 - j;
+#pragma unroll
+        for (int i = 0; i < NPROD; ++i) pair_wait_ge(&prod[i], t + 1, abort_flag, seen_c[i]);
+        const double2* slot = psi_ring[t & (RING - 1)];
+        const double2 pv = slot[lane];
+        double2 qv[N];
+        static_for<0, N>([&](auto q) { qv[decltype(q)::value] = slot[lane ^ (1 << decltype(q)::value)]; });
+        const double2 lm = lam_ring[t & (RING - 1)][lane];
+        double em[CHUNK ? 3 * N : 1];
+        if constexpr (CHUNK) {
+            const double* __restrict__ e = axis_ring + (bl & (kAxisRing - 1)) * (3 * N);
+#pragma unroll
+            for (int i = 0; i < 3 * N; ++i) em[i] = e[i];
+        }
+        if (lane == 0) __hip_atomic_store(&cursor[me], after_v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        mine = __builtin_amdgcn_readfirstlane(after_v);
+        after_v = draw();
+        double acc3[C::KW];
+        products(acc3, pv, qv, lm);
+        if constexpr (CHUNK) {
+            double gx[C::KX];
+#pragma unroll
+            for (int i = 0; i < C::KX; ++i) gx[i] = 0.0;
+            static_for<0, N>([&](auto q) {
+                constexpr int Q = decltype(q)::value;
+                gx[Q] = em[3 * Q] * acc3[3 * Q] + em[3 * Q + 1] * acc3[3 * Q + 1] + em[3 * Q + 2] * acc3[3 * Q + 2];
+            });
+            store_sums(acc3, sub);
+            store_grad_x5(gx, lane, wave, a.B, E, a.grad_x, bl * N, N);
+        } else {
+            store_sums(acc3, sub);
+        }
+    };
+    while (mine < nsteps) {
+        if (LDr == 1 || (mine & 1)) sigma_step(std::true_type{});     // the block's first sub-layer is its last step
+        else sigma_step(std::false_type{});
+    }
+}
+
+template <int LD, int RING, int NSIG>
+__device__ __forceinline__ void zquad_chain(const ZBwdArgs& a, int role /* 0: psi, 1: lambda */, int smp, int lane, bool valid, long b,
+                                            const char* cs_tables, char* my_ring, double2 (*psi_ring)[64], double2 (*lam_ring)[64],
+                                            double2* psi_final, ZQSync* sync, double* axis_ring) {
+    constexpr int N = 5;
+    __builtin_amdgcn_s_setprio(3);
+    const int E = a.E, k = lane & 31, p = lane >> 5;
+    const int ring_fwd = ring_source<N>(lane, false);
+    const int ring_rev = ring_source<N>(lane, true);
+    const unsigned mask4 = lane_sign_mask<4>(lane);
+    SplitStream<LD> ss;
+    ss.init_split(a.srec, a.L + 1, my_ring, lane);
+    const char* row = cs_tables + (smp * (int)zyz_cs_row(N, E) + N) * 32;          // entry of column 0 of this sample's row
+    const int slot_idx = (((smp << 5) | k) << 1) | p;                              // this lane's double in an all-lane slot
+    int seen[NSIG];
+#pragma unroll
+    for (int w = 0; w < NSIG; ++w) seen[w] = 0;
+    double x;
+    if (role == 0) {
+        if (a.state_in) x = a.state_in[(((b << N) + k) << 1) | p];
+        else x = zsplit_forward<LD>(ss, row, a.nblocks, lane, ring_fwd);
+        reinterpret_cast<double*>(psi_final)[slot_idx] = x;
+        handoff_release();
+        if (lane == 0) __hip_atomic_store(&sync->ready[smp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        int seen_ready = 0;
+        pair_wait_ge(&sync->ready[smp], 1, &sync->abort, seen_ready);
+        const double2 f = psi_final[(smp << 5) | k];
+        const double h = ham_weight<N>(k, a.off, a.co, a.diag);
+        double v[1] = {h * (f.x * f.x + f.y * f.y)};
+        lane_reduce<1, 5>(v, lane);                            // over the sample's 32 basis states (both halves hold the sum)
+        const double pred = v[0] + (a.bias ? a.bias[0] : 0.0);
+        if (a.out && valid && lane == 0) a.out[b] = pred;
+        double gb = a.y ? 2.0 * (pred - a.y[b]) * a.inv_bt : a.g[b];
+        if (!valid) gb = 0.0;
+        x = gb * h * (p ? f.y : f.x);
+    }
+    double* ring = reinterpret_cast<double*>(role == 0 ? psi_ring : lam_ring);
+    int* prod = role == 0 ? &sync->psi_prod[smp] : &sync->lam_prod[smp];
+    int step = 0;
+    auto publish_data = [&]() {                                // the state now, the counter after the layer's gates (ztri_chain)
+        if (step >= RING) {
+#pragma unroll
+            for (int w = 0; w < NSIG; ++w)
+                pair_wait_ge(&sync->cursor[w], step - RING + 1, &sync->abort, seen[w]);
+        }
+        ring[(step & (RING - 1)) * 128 + slot_idx] = x;
+        ++step;
+    };
+    auto publish_flag = [&]() {
+        handoff_release();
+        __hip_atomic_store(prod, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // ---- block-unrolled reverse walk in the split layout (the all-lane one: ztri_chain)
+    const int nb = a.nblocks;
+    const unsigned a_dgd = (unsigned)k * 24u + (unsigned)(1 - p) * 8u;             // the inverse diagonal's two entries
+    ss.template prime<-1>(nb, true);
+    split_phase_dag(x, ss.rd8(ss.slot(nb), a_dgd));                                // block nb's slot: its record 0 is the final diagonal
+    ss.template step<-1>(nb);
+    const char* cs_b = row + (long)(nb - 1) * (N * 32);                            // chunk of the block at hand
+    LayerCoef<N> ct, cm, c0;
+    auto read_layer = [&](LayerCoef<N>& c, const char* sl, int rec) {
+        c.dg = ss.rd8(sl, rec * kRecBytes + a_dgd);
+        static_for<0, N>([&](auto q) { c.g[decltype(q)::value] = ss.rd(sl, rec * kRecBytes + ss.a_ry[decltype(q)::value]); });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto read_chunk = [&](const char* sl, const char* chunk) {
+        c0.dg = ss.rd8(sl, a_dgd);
+        static_for<0, N>([&](auto q) { c0.g[decltype(q)::value] = ss.rd(chunk, ss.a_cs[decltype(q)::value]); });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto undo_gates = [&](const LayerCoef<N>& c) {
+        static_rfor<0, N>([&](auto q) { split_ry_dag<decltype(q)::value>(x, c.g[decltype(q)::value], mask4); });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    read_layer(ct, ss.slot(nb - 1), LD);
+    auto block = [&](auto sl, int bl, int kb) {
+        const char* cur = ss.template slot_rel<0>(sl);
+        const char* nx = ss.template slot_rel<-1>(sl);
+        // the chunk-gradient axes of this block (prep_zyz_kernel leaves them in the chunk's split record too): handed to the
+        // sigma waves by the first sample's lambda wave before it publishes the block's first step
+        if (role == 1 && smp == 0 && lane < 3 * N)
+            axis_ring[(bl & (kAxisRing - 1)) * (3 * N) + lane] = reinterpret_cast<const double*>(cur + kSRecRy)[lane];
+        if constexpr (LD == 2) read_layer(cm, cur, 1);
+        else read_chunk(cur, cs_b - kb * (N * 32));
+        x = lane_gather(x, ring_rev);
+        ss.template ahead_rel<-(kBDist + 1)>(sl, bl);          // in the gather's shadow
+        __builtin_amdgcn_sched_barrier(0);
+        publish_data();
+        undo_gates(ct);
+        publish_flag();
+        if constexpr (LD == 2) {
+            read_chunk(cur, cs_b - kb * (N * 32));
+            split_phase_dag(x, ct.dg);
+            x = lane_gather(x, ring_rev);
+            __builtin_amdgcn_sched_barrier(0);
+            publish_data();
+            undo_gates(cm);
+            publish_flag();
+            split_phase_dag(x, cm.dg);
+        } else {
+            split_phase_dag(x, ct.dg);
+        }
+        ss.landed_late();                                     // block bl - 1 landed
+        read_layer(ct, nx, LD);
+        undo_gates(c0);                                       // the RX chunk (every gate in the RY form of the split records)
+        split_phase_dag(x, c0.dg);
+    };
+    int bl = nb - 1;
+    for (; bl >= 0 && (bl & (kBSlots - 1)) != kBSlots - 1; --bl) {
+        block(RtSlot{bl}, bl, 0);
+        cs_b -= N * 32;
+    }
+    for (; bl >= kBSlots - 1; bl -= kBSlots) {
+        block(CtSlot<3>{}, bl, 0);
+        block(CtSlot<2>{}, bl - 1, 1);
+        block(CtSlot<1>{}, bl - 2, 2);
+        block(CtSlot<0>{}, bl - 3, 3);
+        cs_b -= kBSlots * (N * 32);
+    }
+}
+
+template <int RING, int NSIG>
+__global__ __launch_bounds__(64 * (4 + NSIG)) void bwd_zquad_kernel(ZBwdArgs a) {
+    constexpr int N = 5;
+    using C = Cfg<N>;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    char* fixed = dyn_lds;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tid = (int)threadIdx.x;
+    char* rec_ring = fixed;
+    double2 (*psi_ring)[64] = reinterpret_cast<double2 (*)[64]>(fixed + 4 * kBlockRingBytes);
+    double2 (*lam_ring)[64] = reinterpret_cast<double2 (*)[64]>(fixed + 4 * kBlockRingBytes + RING * 1024);
+    double2* psi_final = reinterpret_cast<double2*>(fixed + 4 * kBlockRingBytes + 2 * RING * 1024);
+    ZQSync& sync = *reinterpret_cast<ZQSync*>(fixed + 4 * kBlockRingBytes + 2 * RING * 1024 + 1024);
+    static_assert(sizeof(ZQSync) <= 256, "reserved");
+    double* axis_ring = reinterpret_cast<double*>(fixed + 4 * kBlockRingBytes + 2 * RING * 1024 + 1024 + 256);
+    char* cs_tables = dyn_lds + zquad_fixed_lds(RING);
+    const long wave = blockIdx.x;                              // one sample group (two samples) per workgroup
+    const int E = a.E;
+    if (tid == 0) {
+        sync.psi_prod[0] = sync.psi_prod[1] = sync.lam_prod[0] = sync.lam_prod[1] = 0;
+        sync.ready[0] = sync.ready[1] = 0; sync.abort = 0;
+        for (int w = 0; w < NSIG; ++w) sync.cursor[w] = 0;
+        sync.next = 0;
+    }
+    fill_cs_split(reinterpret_cast<double4*>(cs_tables), a.src, E, wave * C::SPW, a.B, C::SPW, tid, 64 * (4 + NSIG));
+    __syncthreads();
+
+    if (wv < 4) {
+        const int role = wv >> 1, smp = wv & 1;
+        const long b_raw = wave * C::SPW + smp;
+        const bool valid = b_raw < a.B;
+        const long b = valid ? b_raw : a.B - 1;
+        char* my_ring = rec_ring + wv * kBlockRingBytes;
+        if (a.fast_ld == 2) zquad_chain<2, RING, NSIG>(a, role, smp, lane, valid, b, cs_tables, my_ring, psi_ring, lam_ring, psi_final, &sync, axis_ring);
+        else zquad_chain<1, RING, NSIG>(a, role, smp, lane, valid, b, cs_tables, my_ring, psi_ring, lam_ring, psi_final, &sync, axis_ring);
+    } else {
+        zsigma_walk<RING, 4>(a, lane, wv - 4, wave, psi_ring, lam_ring, axis_ring, &sync.psi_prod[0], &sync.abort, sync.cursor, &sync.next);
+    }
+    report_abort(&sync.abort, a.status, lane);
+}
+
+// ---------------------------------------------------------------------------------------
 // One-wave-per-sample-group backward kernel in the ZYZ form, for batches that fill the SIMDs (AUTO: more sample
 // groups than SIMDs; block-unrolled shapes only, others keep bwd_kernel of hea_device.hpp).  At those batches the
 // first-generation packed kernel is bound by the CU's single LDS pipe (per sample group and block ~170 LDS
@@ -1490,6 +1783,7 @@ __global__ __launch_bounds__(kZPWaves * 64) void fwd_zshared_kernel(ZFwdArgs a) 
     void launch_bwd_zpacked_##NN(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a);
 QHEA_FOR_EACH_ZN(QHEA_ZDECLARE)
 void launch_fwd_split_5(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArgs& a);
+void launch_bwd_zquad_5(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a);
 #undef QHEA_ZDECLARE
 
 }  // namespace qhea

@@ -50,7 +50,8 @@ def _oracle_adam_loop(model_cpu, names, branch, trunk, y, bounds, gbs, n, net, l
     return np.stack(rows), np.concatenate([p.detach().numpy().reshape(-1) for p in params])
 
 
-@pytest.mark.parametrize('batch,variant', [(1024, 'auto'), (512, 'auto'), (1000, 'auto'), (1024, 'ztri')])
+@pytest.mark.parametrize('batch,variant', [(1024, 'auto'), (512, 'auto'), (1000, 'auto'), (1024, 'ztri'), (512, 'ztri'),
+                                           (100, 'auto'), (1024, 'zquad'), (333, 'zquad'), (1280, 'auto')])
 def test_benched_train_steps_match_oracle_and_torch_adam(dev, batch, variant):
     from quanonet_amd.models import QuanONetPT
     from quanonet_amd.solver import DataParallelTrainer

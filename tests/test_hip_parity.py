@@ -36,7 +36,7 @@ def _run(n, cfgs, x, w, g, dev, off, co, diag=None, use_state=True, pauli='Z'):
     return (out.cpu().numpy(), st.cpu().numpy(), gx.cpu().numpy(), gw.cpu().numpy(), out2.cpu().numpy())
 
 
-@pytest.fixture(params=['packed', 'pair', 'tri', 'ztri', 'zpacked'])
+@pytest.fixture(params=['packed', 'pair', 'tri', 'ztri', 'zpacked', 'zquad'])
 def backward_variant(request, dev):
     """The backward kernels for n <= 5 (one wave per sample group, the psi-wave / lambda-wave pipeline, the
     psi / lambda / sigma three-wave pipeline, and that pipeline on the ZYZ form of the gates -- 'ztri', which with

@@ -28,7 +28,7 @@ model = QuanONetPT(5, 8, 2, (3, 2, 2, 2), scale_coeff=0.1, if_trainable_freq=Tru
 tr = DataParallelTrainer(model, lr=1e-2, fused=True)
 br = torch.tensor(rng.normal(size=(B, 8)), device=dev); tk = torch.tensor(rng.uniform(size=(B, 2)), device=dev)
 y = torch.tensor(rng.normal(size=B), device=dev)
-for variant in ('ztri', 'tri', 'pair'):
+for variant in ('ztri', 'zquad', 'auto', 'tri', 'pair'):
     _lib.set_backward_variant(variant)
     before = tr.pflat.clone()
     flat = tr.train_step(br, tk, y).clone()                     # qhea_model_train_step: Adam fused into the reduce kernel
@@ -95,7 +95,7 @@ def test_status_is_clean_after_healthy_runs():
     rng = np.random.default_rng(1)
     x = torch.tensor(rng.uniform(-3, 3, (200, 10)), device=dev); w = torch.tensor(rng.uniform(-3, 3, (4, 3, 5)), device=dev)
     g = torch.ones(200, dtype=torch.float64, device=dev)
-    for v in ('ztri', 'zpacked', 'tri', 'pair', 'packed', 'auto'):
+    for v in ('ztri', 'zquad', 'zpacked', 'tri', 'pair', 'packed', 'auto'):
         _lib.set_backward_variant(v)
         for _ in range(20):
             gx, gw = _lib.hea_backward(sh, x, w, g, 0.0, 1.0)
