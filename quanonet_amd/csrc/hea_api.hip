@@ -514,16 +514,17 @@ Layout make_layout(int n, const Shape& sh, int64_t B) {
     }
     L.zL = zok ? zyz_layer_count(sh.runs, n) : 0;
     L.zsplit = zok && zsplit_eligible(n, sh.E, sh.runs);
-    // Two pipelines per workgroup (their sigma waves add the two groups' sums in LDS: half the partial rows, -6 MB of HBM
-    // traffic per cfg-2 step, bwd_ztri_kernel<N, 2>).  Measured at cfg 2 (us per step, one / two pipelines): B = 1024
-    // 103.1 / 103.3, 960 103.3 / 103.7, 896 102.6 / 103.2, 768 101.8 / 102.6, 640 99.9 / 101.5, 1280 156 / 189 -- a wash
-    // where every CU holds two sample groups anyway, a loss elsewhere (10-wave workgroups, one per CU).  AUTO therefore takes
-    // two pipelines only when the groups fill more than 7/8 of the CUs' two slots; QHEA_BWD_ZTRI2 forces them wherever two
-    // workgroups would share a CU, QHEA_BWD_ZTRI never.
+    // Two pipelines per workgroup (bwd_ztri_kernel<N, 2>: their sigma waves add the two groups' sums in LDS, half the partial
+    // rows).  With the chain waves laid out as the workgroup's waves 0..3 every SIMD hosts exactly ONE of the CU's four chain
+    // waves; two separate five-wave workgroups (and round 2's pipeline-by-pipeline layout of the ten) put two chains on one
+    // SIMD, and the pipeline runs at the pace of its slowest chain.  cfg 2, us per training step, two pipelines per workgroup /
+    // one: B = 520 89.5 / 96.1, 640 90.0 / 97.8, 768 90.6 / 98.5, 896 91.1 / 99.3, 1024 91.3 / 101.1 (profiles/r03_batch_sweep.txt)
+    // -- so AUTO takes two pipelines wherever the batch has more sample groups than the device has CUs (up to two per CU; beyond
+    // that the one-pipeline workgroups run in two rounds, 154 us at 1280).  QHEA_BWD_ZTRI2 forces them, QHEA_BWD_ZTRI never.
     L.zpipes = 1;
     const long cus = (long)simd_count() / 4;
     const bool two_wanted = var == QHEA_BWD_ZTRI2 ? L.nwaves > cus
-                                                  : (var == QHEA_BWD_AUTO && 8 * L.nwaves > 14 * cus && L.nwaves <= 2 * cus);
+                                                  : (var == QHEA_BWD_AUTO && L.nwaves > cus && L.nwaves <= 2 * cus);
     if (L.ztri && two_wanted) {
         const size_t cs_bytes = (size_t)(64 >> n) * zyz_cs_row(n, sh.E) * (L.zsplit ? 32 : 16);
         const size_t lds = 2 * ztri_fixed_lds(kZRingDepth<2>) + 2 * cs_bytes +

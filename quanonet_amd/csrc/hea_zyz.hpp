@@ -732,7 +732,13 @@ __global__ __launch_bounds__((kWaves + kFwdHelpers) * 64) void fwd_zyz_kernel(ZF
 
 // Forward kernel in the split layout (n = 5, block-unrolled shapes, Z / diagonal read-out): one sample per sweeping
 // wave, kSplitWaves of them per workgroup + helpers for the table fill.  For batches that leave SIMDs free.
-constexpr int kSplitWaves = 2, kSplitHelpers = 2;
+#ifndef QHEA_SPLIT_WAVES
+#define QHEA_SPLIT_WAVES 4
+#endif
+#ifndef QHEA_SPLIT_HELPERS
+#define QHEA_SPLIT_HELPERS 2
+#endif
+constexpr int kSplitWaves = QHEA_SPLIT_WAVES, kSplitHelpers = QHEA_SPLIT_HELPERS;
 template <int N>
 __global__ __launch_bounds__((kSplitWaves + kSplitHelpers) * 64) void fwd_split_kernel(ZFwdArgs a) {
     static_assert(N == 5, "split layout: n = 5");
@@ -1011,9 +1017,26 @@ constexpr int kZPipeWaves = 2 + kZSigma;
 __host__ __device__ constexpr size_t ztri_fixed_lds(int ring) {
     return 2 * (size_t)kBlockRingBytes + 2 * (size_t)ring * 1024 + 1024 + 256 + (size_t)kAxisRing * 15 * sizeof(double);
 }
+// Wave -> (pipeline, role) of bwd_ztri_kernel.  PIPES = 2 (QHEA_ZTRI2_MAP = 1): the four chain waves are the workgroup's
+// waves 0..3 (psi A, lambda A, psi B, lambda B) and the sigma waves follow, three per pipeline: a workgroup's waves go to
+// the SIMDs in cyclic order, so every SIMD gets exactly one chain wave (with roles laid out pipeline by pipeline, waves 0, 1,
+// 5, 6 were the chains: two of them on one SIMD).
+#ifndef QHEA_ZTRI2_MAP
+#define QHEA_ZTRI2_MAP 1
+#endif
 template <int PIPES>
 __device__ __forceinline__ int pipe_of_wave() {
-    return PIPES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) / kZPipeWaves;
+    if constexpr (PIPES == 1) return 0;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (QHEA_ZTRI2_MAP) return wv < 4 ? (wv >> 1) : (wv - 4) / kZSigma;
+    return wv / kZPipeWaves;
+}
+template <int PIPES>
+__device__ __forceinline__ int role_of_wave() {          // 0: psi, 1: lambda, 2..: sigma
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if constexpr (PIPES == 1) return wv;
+    if (QHEA_ZTRI2_MAP) return wv < 4 ? (wv & 1) : 2 + (wv - 4) % kZSigma;
+    return wv % kZPipeWaves;
 }
 template <int PIPES> constexpr int kZRingDepth = PIPES == 1 ? kPairRing : 8;      // LDS: 2 x (24 + 16 + 20) KB + the row
 template <int N, int PIPES>
@@ -1029,10 +1052,9 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
     char* lds_tables = dyn_lds + PIPES * (int)ztri_fixed_lds(RING);
 
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int pipe = PIPES == 1 ? 0 : wv / kZPipeWaves;
-    const int role = PIPES == 1 ? wv : wv % kZPipeWaves;                           // 0: psi, 1: lambda, 2..: sigma
-    const int tid = (int)threadIdx.x - pipe * (64 * kZPipeWaves);                  // within the pipeline
+    const int pipe = pipe_of_wave<PIPES>();
+    const int role = role_of_wave<PIPES>();                                        // 0: psi, 1: lambda, 2..: sigma
+    const int tid = role * 64 + lane;                                              // within the pipeline
     char* rec_ring = fixed;
     double2 (*psi_ring)[64] = reinterpret_cast<double2 (*)[64]>(fixed + 2 * kBlockRingBytes);
     double2 (*lam_ring)[64] = reinterpret_cast<double2 (*)[64]>(fixed + 2 * kBlockRingBytes + RING * 1024);
@@ -1233,7 +1255,7 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
 #ifdef QHEA_PROFILE_WAITS
     if (blockIdx.x == 100 && lane == 0)
         printf("role %d: total %llu ticks, in waits %llu ticks, %llu waits that read the counter (%llu of them spun)\n", role,
-               __builtin_amdgcn_s_memtime() - t_begin, sync.waited[2 * wv], sync.waited[2 * wv + 1] & 0xffffffffull, sync.waited[2 * wv + 1] >> 32);
+               __builtin_amdgcn_s_memtime() - t_begin, sync.waited[2 * (threadIdx.x >> 6)], sync.waited[2 * (threadIdx.x >> 6) + 1] & 0xffffffffull, sync.waited[2 * (threadIdx.x >> 6) + 1] >> 32);
 #endif
     report_abort(&sync.abort, a.status, lane);
     if constexpr (PIPES > 1) {
