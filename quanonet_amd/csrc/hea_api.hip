@@ -593,8 +593,8 @@ int launch_zyz_forward(int n, const Shape& sh, int64_t B, const Layout& L, char*
         }
         return QHEA_OK;
     }
-    const dim3 grid((unsigned)(L.nwaves_fwd / kWaves));
-    const size_t dyn = (size_t)kWaves * (64 >> n) * zyz_cs_row(n, sh.E) * sizeof(double2);
+    const dim3 grid((unsigned)((L.nwaves_fwd + kZFwdWaves - 1) / kZFwdWaves));
+    const size_t dyn = (size_t)kZFwdWaves * (64 >> n) * zyz_cs_row(n, sh.E) * sizeof(double2);
     switch (n) {
 #define QHEA_CASE(NN) case NN: launch_fwd_zyz_##NN(grid, dyn, st, za); break;
         QHEA_FOR_EACH_ZN(QHEA_CASE)

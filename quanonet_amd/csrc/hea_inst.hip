@@ -46,7 +46,7 @@ void QHEA_CAT(launch_bwd_pair_, QHEA_N)(dim3 grid, hipStream_t st, const BwdArgs
 
 #if QHEA_N <= 5
 void QHEA_CAT(launch_fwd_zyz_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArgs& a) {
-    hipLaunchKernelGGL(fwd_zyz_kernel<QHEA_N>, grid, dim3((kWaves + kFwdHelpers) * 64), dyn_lds, st, a);
+    hipLaunchKernelGGL(fwd_zyz_kernel<QHEA_N>, grid, dim3((kZFwdWaves + kFwdHelpers) * 64), dyn_lds, st, a);
 }
 void QHEA_CAT(launch_bwd_ztri_, QHEA_N)(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a) {
     if (a.pipes == 2) hipLaunchKernelGGL((bwd_ztri_kernel<QHEA_N, 2>), grid, dim3(2 * 64 * kZPipeWaves), dyn_lds, st, a);
@@ -63,7 +63,6 @@ void launch_fwd_split_5(dim3 grid, size_t dyn_lds, hipStream_t st, const ZFwdArg
     hipLaunchKernelGGL(fwd_split_kernel<5>, grid, dim3((kSplitWaves + kSplitHelpers) * 64), dyn_lds, st, a);
 }
 void launch_bwd_zquad_5(dim3 grid, size_t dyn_lds, hipStream_t st, const ZBwdArgs& a) {
-    // three sigma waves: with two they bound the reverse phase (87 us per cfg-2 step at B = 512 against 77), a fourth changes nothing
     hipLaunchKernelGGL((bwd_zquad_kernel<kPairRing, kZSigma>), grid, dim3(64 * (4 + kZSigma)), dyn_lds, st, a);
 }
 #endif

@@ -72,13 +72,14 @@ __device__ __forceinline__ double enc_angle(const AngleSrc& a, int E, long b, in
 __device__ __forceinline__ void fill_cs(double2* cs, const AngleSrc& src, int n, int E, long b0, long B, int ns, int tid, int nthreads,
                                         int row_stride = 0 /* 0: zyz_cs_row(n, E) */) {
     const int row = row_stride ? row_stride : (int)zyz_cs_row(n, E);
-    for (int s = 0; s < ns; ++s) {
+    // (sample, column) pairs spread over the threads: short rows (cfg 1: E = 20) would leave most threads idle in a loop over
+    // columns only, and the sweeps cannot start before the fill is done
+    for (int i = tid; i < ns * E; i += nthreads) {
+        const int s = i / E, e = i - s * E;
         const long b = (b0 + s < B) ? b0 + s : B - 1;
-        for (int e = tid; e < E; e += nthreads) {
-            double sn, cn;
-            sincos(0.5 * enc_angle(src, E, b, e), &sn, &cn);
-            cs[s * row + n + e] = make_double2(cn, sn);
-        }
+        double sn, cn;
+        sincos(0.5 * enc_angle(src, E, b, e), &sn, &cn);
+        cs[s * row + n + e] = make_double2(cn, sn);
     }
 }
 
@@ -170,14 +171,16 @@ template <int CNT>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CNT) : "memory"); }
 
 constexpr int kSlots = 8, kDist = 6;
-// sigma waves per pipeline of bwd_ztri_kernel.  The sigma waves bound the reverse phase (they never wait for the chains after
-// their first step, the chains do wait for ring slots: DESIGN.md 3.4), so a third one pays -- once two 5-wave workgroups fit
-// a CU, which takes <= 128 VGPRs (four wave slots per SIMD; the kernel's LDS is all dynamic so that the compiler does not cap
-// its occupancy estimate at the LDS limit, and the walks keep one layer's coefficients ahead instead of a block's).
-// cfg 2, us per launch with 2 / 3 / 4 sigma waves (steps drawn from a counter): B = 512 74.0 / 70.2 / 72.3, B = 1024 94.6 / 90.4 / 92.1,
-// B = 1536 149 / 141 / 158.
+// sigma waves per pipeline of bwd_ztri_kernel / bwd_zquad_kernel.  Round 2 settled on three: the sigma waves bounded the reverse
+// phase with two, and a fourth did not pay (B = 1024: 94.6 / 90.4 / 92.1 us per launch with 2 / 3 / 4).  That was measured with
+// two chain waves sharing a SIMD (pipe_of_wave); with every chain wave on a SIMD of its own FOUR sigma waves per pipeline -- two
+// per SIMD beside its one chain wave in the two-pipeline workgroup -- are the best: cfg 2, us per training step with
+// 2 / 3 / 4 / 5 / 6 sigma waves: B = 1024 94.1 / 91.4 / 88.9 / 90.0 / 91.5, B = 512 (quad-chain kernel) 89.1 / 76.2 / 74.2 / 76.2 / 77.4
+// (scripts/exp/small_batch_steps.py on -DQHEA_ZSIGMA=n builds).  The kernels stay under 128 VGPRs (all of their LDS is dynamic,
+// so that the compiler does not cap its occupancy estimate at the LDS limit; the walks keep one layer's coefficients ahead
+// instead of a block's), so a CU's twelve waves have room.
 #ifndef QHEA_ZSIGMA
-#define QHEA_ZSIGMA 3
+#define QHEA_ZSIGMA 4
 #endif
 constexpr int kZSigma = QHEA_ZSIGMA;
 constexpr int kAxisRing = 16;                   // blocks whose RX-gradient axes (15 doubles) are kept for the sigma waves: > ring depth / LD
@@ -521,13 +524,12 @@ __host__ __device__ inline bool zsplit_eligible(int n, long E, const Runs& r) {
 }
 __device__ __forceinline__ void fill_cs_split(double4* cs, const AngleSrc& src, int E, long b0, long B, int ns, int tid, int nthreads) {
     const int row = (int)zyz_cs_row(5, E);
-    for (int s = 0; s < ns; ++s) {
+    for (int i = tid; i < ns * E; i += nthreads) {              // (sample, column) pairs spread over the threads (fill_cs)
+        const int s = i / E, e = i - s * E;
         const long b = (b0 + s < B) ? b0 + s : B - 1;
-        for (int e = tid; e < E; e += nthreads) {
-            double sn, cn;
-            sincos(0.5 * enc_angle(src, E, b, e), &sn, &cn);
-            cs[s * row + 5 + e] = (e % 5 == 4) ? make_double4(sn, cn, cn, -sn) : make_double4(cn, -sn, cn, sn);
-        }
+        double sn, cn;
+        sincos(0.5 * enc_angle(src, E, b, e), &sn, &cn);
+        cs[s * row + 5 + e] = (e % 5 == 4) ? make_double4(sn, cn, cn, -sn) : make_double4(cn, -sn, cn, sn);
     }
 }
 // what the all-lane gates (apply_enc) want from a 32-byte entry: (cos, sin)
@@ -677,26 +679,28 @@ struct ZBwdArgs {
     int pipes;                  // bwd_ztri_kernel: sample groups per workgroup (1 or 2)
 };
 
-// kWaves sweeping waves + kFwdHelpers waves that only help to fill the (cos, sin) tables and then leave: the fill is
-// 2 x 600 fp64 sincos at cfg 2, ~4 us if each sweeping wave does its own, and the sweep cannot start before it.
-constexpr int kFwdHelpers = 2;
+// kZFwdWaves sweeping waves + kFwdHelpers waves that only help to fill the (cos, sin) tables and then leave: the fill is
+// 2 x 600 fp64 sincos per sweeping wave at cfg 2, ~4 us if each does its own, and the sweep cannot start before it.  Four
+// sweeping waves: a workgroup's waves go to the CU's SIMDs in cyclic order, so each sweep gets a SIMD of its own; with two per
+// workgroup the dispatcher put sweeps of co-resident workgroups on one SIMD while another stood empty.
+constexpr int kFwdHelpers = 2, kZFwdWaves = 4;
 template <int N>
-__global__ __launch_bounds__((kWaves + kFwdHelpers) * 64) void fwd_zyz_kernel(ZFwdArgs a) {
+__global__ __launch_bounds__((kZFwdWaves + kFwdHelpers) * 64) void fwd_zyz_kernel(ZFwdArgs a) {
     using C = Cfg<N>;
     static_assert(C::R == 1, "all-lane layout");
-    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // kWaves x SPW x E (cos, sin)
-    __shared__ __attribute__((aligned(16))) char rec_ring[kWaves * kBlockRingBytes];
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];                 // kZFwdWaves x SPW x E (cos, sin)
+    __shared__ __attribute__((aligned(16))) char rec_ring[kZFwdWaves * kBlockRingBytes];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     {
         const int csrow_len = (int)zyz_cs_row(N, a.E);
-        fill_cs(reinterpret_cast<double2*>(dyn_lds), a.src, N, a.E, (long)blockIdx.x * kWaves * C::SPW, a.B, kWaves * C::SPW,
-                (int)threadIdx.x, (kWaves + kFwdHelpers) * 64);
+        fill_cs(reinterpret_cast<double2*>(dyn_lds), a.src, N, a.E, (long)blockIdx.x * kZFwdWaves * C::SPW, a.B, kZFwdWaves * C::SPW,
+                (int)threadIdx.x, (kZFwdWaves + kFwdHelpers) * 64);
         (void)csrow_len;
     }
     __syncthreads();
-    if (wib >= kWaves) return;
-    const long wave = (long)blockIdx.x * kWaves + wib;
+    if (wib >= kZFwdWaves) return;
+    const long wave = (long)blockIdx.x * kZFwdWaves + wib;
     const long b_raw = wave * C::SPW + (lane >> C::LB);
     const bool valid = b_raw < a.B;
     const long b = valid ? b_raw : a.B - 1;
@@ -1282,7 +1286,7 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
 // Daggered split gates: RY(theta)^-1 flips the sign of the partner's coefficient (wire 4's swap form: x' = +-(u.x A - u.y B),
 // - for the lanes with bit 4 set); a diagonal's inverse reads the other two of its record's three entries [-sin, cos, sin].
 // ---------------------------------------------------------------------------------------
-struct ZQSync { int psi_prod[2], lam_prod[2], ready[2], abort; int cursor[4]; int next; };
+struct ZQSync { int psi_prod[2], lam_prod[2], ready[2], abort; int cursor[8]; int next; };
 __host__ __device__ constexpr size_t zquad_fixed_lds(int ring) {
     return 4 * (size_t)kBlockRingBytes + 2 * (size_t)ring * 1024 + 1024 + 256 + (size_t)kAxisRing * 15 * sizeof(double);
 }
