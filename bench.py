@@ -444,6 +444,14 @@ def main():
         if roof.get('traffic') is not None:
             roof['traffic_source'] = pmc_src
 
+    # the clock this device's shader engines run at inside a kernel (diagnostic: devices of one model differ by several
+    # percent, and the latency-bound kernels with them -- the box-to-box spread of these numbers)
+    clock = None
+    if rank == 0:
+        med, lo, hi = _lib.clock_probe(dev)
+        clock = {"in_kernel_clock_mhz_median": med, "min": lo, "max": hi,
+                 "how": "1024 one-wave workgroups, dependent fp64 FMA chain, s_memtime / s_memrealtime x 100 MHz (qhea_clock_probe)"}
+
     secondary = None
     if world == 1 and not args.no_secondary and batch == BATCH and args.backward_variant == 'auto':
         def measure_many(fn, k, budget_s):
@@ -488,7 +496,7 @@ def main():
                                     if os.environ.get('QHEA_BENCH_PER_STEP') else
                                     "the resident set in chunks of one batch per host call (qhea_model_forward_chunks, what "
                                     "PTSolver.predict runs: one record preparation per call, one forward launch per batch)"),
-            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
+            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary, "device_clock": clock,
         }
         print(json.dumps(line))
     if trainer.peer is not None:

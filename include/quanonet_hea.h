@@ -116,6 +116,14 @@ int qhea_check_status(void* workspace /*DEVICE*/, size_t workspace_bytes, void* 
 int qhea_profile_next_circuit_kernel(void* start_event, void* stop_event);
 
 /*
+ * Diagnostic (no reference counterpart): n_workgroups one-wave workgroups each time a dependent fp64 FMA chain of `iters`
+ * steps with the shader-clock counter and with the constant 100 MHz counter; ticks[2 w] / ticks[2 w + 1] x 100 MHz is the clock
+ * workgroup w ran at.  bench.py prints the median, so that a step time can be read against the clock of the device it ran on
+ * (devices of one model differ by several percent, and so do the latency-bound kernels here).
+ */
+int qhea_clock_probe(int n_workgroups, int64_t iters, unsigned long long* ticks /*DEVICE [2 * n_workgroups]*/, void* stream);
+
+/*
  * Bytes of DEVICE scratch the calls below need for this circuit shape and batch.
  * Replaces: nothing in the reference (TorchQuantum allocates per-gate temporaries and
  * autograd saves every intermediate state; core/quantum_circuits_tq.py:74).

@@ -29,7 +29,7 @@ EXPORTS = ['qhea_version', 'qhea_strerror', 'qhea_device_count', 'qhea_workspace
            'qhea_profile_next_circuit_kernel',
            'qhea_adam_step', 'qhea_set_backward_variant', 'qhea_check_status',
            'qhea_dp_buffer_bytes', 'qhea_dp_alloc', 'qhea_dp_free', 'qhea_dp_export', 'qhea_dp_import', 'qhea_dp_close',
-           'qhea_dp_allreduce_adam', 'qhea_dp_status', 'qhea_model_dp_train_steps']
+           'qhea_dp_allreduce_adam', 'qhea_dp_status', 'qhea_model_dp_train_steps', 'qhea_clock_probe']
 
 
 class ModelDesc(ctypes.Structure):
@@ -134,6 +134,8 @@ def load():
                                               ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                               ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, vpp,
                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_double, vp, ctypes.c_size_t, vp]
+    lib.qhea_clock_probe.restype = ctypes.c_int
+    lib.qhea_clock_probe.argtypes = [ctypes.c_int, ctypes.c_int64, vp, vp]
     lib.qhea_model_param_count.restype = ctypes.c_int64
     lib.qhea_model_param_count.argtypes = [mdp]
     lib.qhea_model_workspace_bytes.restype = ctypes.c_size_t
@@ -476,6 +478,19 @@ def model_dp_train_steps(desc, bounds, global_batches, branch, trunk, y, params,
         raise Unsupported("qhea_model_dp_train_steps: empty shard or reduce grid not resident at once")
     _check(rc, 'qhea_model_dp_train_steps')
     return rows
+
+
+def clock_probe(device, n_workgroups=1024, iters=200000):
+    """In-kernel shader clock in MHz (median over `n_workgroups` one-wave workgroups timing a dependent fp64 FMA chain against
+    the constant 100 MHz counter; qhea_clock_probe).  A diagnostic: the latency-bound kernels scale with it."""
+    buf = torch.zeros(2 * n_workgroups, dtype=torch.int64, device=device)
+    with torch.cuda.device(device):
+        _check(load().qhea_clock_probe(int(n_workgroups), int(iters), ctypes.c_void_p(buf.data_ptr()), _stream(device)),
+               'qhea_clock_probe')
+    t = buf.cpu().numpy().reshape(-1, 2).astype('float64')
+    mhz = 100.0 * t[:, 0] / t[:, 1]
+    import numpy as _np
+    return float(_np.median(mhz)), float(mhz.min()), float(mhz.max())
 
 
 def profile_next_circuit_kernel(start_event, stop_event):

@@ -855,6 +855,19 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
     }
 }
 
+// Diagnostic: the clock the shader engines actually run at, measured inside a kernel.  Every workgroup times a dependent fp64
+// FMA chain with s_memtime (shader-clock ticks) against s_memrealtime (the constant 100 MHz counter); the ratio x 100 MHz is
+// its in-kernel clock (MI355X_MICROARCH.md, clocks section: devices of one model differ by up to ~12 % there, which is the
+// box-to-box spread of the latency-bound kernels here).  bench.py reports the median over the workgroups.
+__global__ __launch_bounds__(64) void clock_probe_kernel(long iters, unsigned long long* out) {
+    double x = 1.0 + 1e-9 * threadIdx.x, y = 1.0 - 1e-12;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (long i = 0; i < iters; ++i) x = fma(x, y, 1e-13);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = t1 - t0; out[2 * blockIdx.x + 1] = r1 - r0; }
+    if (x == 123.456) out[0] = 0;                        // keep the chain
+}
+
 struct ModelInfo {
     Shape sh;
     int n = 0;
@@ -984,6 +997,12 @@ int qhea_profile_next_circuit_kernel(void* start_event, void* stop_event) {
     g_ev_start = static_cast<hipEvent_t>(start_event);
     g_ev_stop = static_cast<hipEvent_t>(stop_event);
     return QHEA_OK;
+}
+
+int qhea_clock_probe(int n_workgroups, int64_t iters, unsigned long long* ticks /*DEVICE [2 * n_workgroups]*/, void* stream) {
+    if (n_workgroups < 1 || iters < 1 || !ticks) return QHEA_EINVAL;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3((unsigned)n_workgroups), dim3(64), 0, static_cast<hipStream_t>(stream), (long)iters, ticks);
+    return hipGetLastError() == hipSuccess ? QHEA_OK : QHEA_ELAUNCH;
 }
 
 int qhea_set_backward_variant(int variant) {
