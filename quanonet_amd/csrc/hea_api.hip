@@ -459,10 +459,11 @@ bool use_pair(int n, int64_t B) {
     const int v = g_bwd_variant.load(std::memory_order_relaxed);
     if (v == QHEA_BWD_PACKED || v == QHEA_BWD_ZPACKED) return false;
     if (v == QHEA_BWD_PAIR || v == QHEA_BWD_TRI || v == QHEA_BWD_ZTRI || v == QHEA_BWD_ZTRI2 || v == QHEA_BWD_ZQUAD) return true;
-    // measured at n = 5 (us per backward call incl. prep/reduce; packed / pipelined): B = 1024 194 / 155, B = 1536
-    // 247 / 181, B = 2048 260 / 273 -- pipelined while the sample groups fill at most 3/4 of the SIMDs
+    // measured at n = 5, cfg 2's circuit (us per training step, pipelined in two rounds / one wave per group,
+    // profiles/r03_batch_sweep.txt): B = 1100 153.8 / 156.0, 1280 154.9 / 157.4, 1536 164.0 / 158.3, 1792 231.6 / 160.5 --
+    // pipelined while the sample groups fill at most 5/8 of the SIMDs (2.5 per CU)
     const int spw = 64 >> lane_bits(n);
-    return 4 * ((B + spw - 1) / spw) <= 3 * (int64_t)simd_count();
+    return 8 * ((B + spw - 1) / spw) <= 5 * (int64_t)simd_count();
 }
 
 // Workgroup-resident kernels (hea_lds.hip) for n >= 10; the wave-resident ones are built for n <= 9 only.
