@@ -197,7 +197,8 @@ def secondary_configs(dev, measure_many):
                'num_epochs': 1, 'if_save': False, 'prefix': tempfile.mkdtemp()}
         set_random_seed(0)
         sv = PTSolver(cfg, data, device=dev, log=lambda *a, **k: None)
-        sv.train()                                               # warm-up epoch
+        sv.config['num_epochs'] = 4 if bs >= 512 else 1          # warm-up: >= 30 ms of load (the clock ramps that long after idle)
+        sv.train()
         torch.cuda.synchronize()
         sv.config['num_epochs'] = epochs
         t0 = time.perf_counter()
