@@ -298,3 +298,82 @@ def test_fused_step_with_a_missing_peer_fails_on_every_rank():
     for rank, all_nan, untouched, raised in res:
         assert all_nan and untouched, (rank, all_nan, untouched)
         assert raised is not None and ('(-7)' in raised or 'peer rank' in raised)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE cfg 3 / cfg 5 in their data-parallel form, as far as one GPU allows: the stated per-GPU shard (512 rows of the
+# Q5 Net40-2-20-2 model; a few rows of the Q12 one) on every rank, the GLOBAL batch in the loss weight, ranks sharing the
+# device -- against the oracle + torch.optim.Adam on the whole global batch
+# ------------------------------------------------------------------------------------------------------------------
+def _shard_worker(rank, world, port, q, nq, per_rank, steps):
+    dist = _init(rank, world, port)
+    from quanonet_amd.models import QuanONetPT
+    from quanonet_amd.solver import DataParallelTrainer
+    dev = torch.device('cuda', 0)
+    net, b_in, t_in = (40, 2, 20, 2), 100, 2
+    gb = per_rank * world
+    rng = np.random.default_rng(3)                                  # the same global data on every rank
+    branch = rng.normal(size=(steps * gb, b_in)); trunk = rng.uniform(size=(steps * gb, t_in))
+    y = rng.normal(scale=0.5, size=(steps * gb, 1))
+    torch.manual_seed(0)
+    model = QuanONetPT(nq, b_in, t_in, net, scale_coeff=0.1, if_trainable_freq=True).double().to(dev)
+    tr = DataParallelTrainer(model, lr=1e-3, world_size=world, dist=dist)
+    assert tr.peer is not None, tr.dp_exchange_reason
+    tr.peer_fused = False                                           # ranks share the GPU here: the separate exchange kernel
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    rows = []
+    for i in range(steps):
+        lo = i * gb + rank * per_rank
+        flat = tr.train_step(t(branch[lo:lo + per_rank]), t(trunk[lo:lo + per_rank]), t(y[lo:lo + per_rank]), global_batch=gb)
+        rows.append(flat.clone())
+    torch.cuda.synchronize()
+    tr.check_status()
+    q.put((rank, torch.stack(rows).cpu().numpy(), tr.pflat.cpu().numpy()))
+    dist.barrier()
+    tr.peer.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,nq,per_rank,steps', [(4, 5, 512, 2), (2, 12, 6, 2)])
+def test_data_parallel_shards_at_the_baseline_configs_match_the_oracle(world, nq, per_rank, steps):
+    """cfg 3 (Darcy-shaped Q5 Net40-2-20-2, 512 rows per GPU; 4 of its 8 ranks fit the one-GPU box's process limit) and
+    cfg 5's model (Q12, a few rows per rank): every step's GLOBAL [grads | sse | sum y^2] row and the final parameters
+    against oracle gradients + torch.optim.Adam over the whole global batch, 1e-9."""
+    from oracle import hea_oracle as O
+    from oracle import c_oracle as C
+    res = _spawn(_shard_worker, world, extra=(nq, per_rank, steps))
+    net, b_in, t_in = (40, 2, 20, 2), 100, 2
+    gb = per_rank * world
+    rng = np.random.default_rng(3)
+    branch = rng.normal(size=(steps * gb, b_in)); trunk = rng.uniform(size=(steps * gb, t_in))
+    y = rng.normal(scale=0.5, size=(steps * gb, 1))[:, 0]
+    # initial parameters exactly as the workers' QuanONetPT constructor draws them under the same seed (the ansatz angles are
+    # torch's first draw after manual_seed, in float32: core/quantum_circuits_tq.py:50-53; frequency weights = scale, biases 0)
+    import torch.nn as nn
+    torch.manual_seed(0)
+    w32 = torch.empty(120, 3, nq); nn.init.uniform_(w32, -np.pi, np.pi)
+    bd, bl, td, tl = net
+    params = {'bias': torch.zeros(1, dtype=torch.float64),
+              'branch_freq.weights': torch.full((bd * nq,), 0.1, dtype=torch.float64), 'branch_freq.bias': torch.zeros(bd * nq, dtype=torch.float64),
+              'trunk_freq.weights': torch.full((td * nq,), 0.1, dtype=torch.float64), 'trunk_freq.bias': torch.zeros(td * nq, dtype=torch.float64),
+              'quantum_layer.ansatz_weights': w32.double()}
+    names = list(params)                                             # nn.Module.parameters() order of QuanONetPT
+    tp = [nn.Parameter(v.clone()) for v in params.values()]
+    opt = torch.optim.Adam(tp, lr=1e-3)
+    want_rows = []
+    for i in range(steps):
+        lo, hi = i * gb, (i + 1) * gb
+        sd = {k: p.detach().numpy() for k, p in zip(names, tp)}
+        loss, grads, _ = O.quanonet_loss_and_grads(sd, branch[lo:hi], trunk[lo:hi], y[lo:hi], nq, net, engine=C)
+        flat = np.concatenate([np.asarray(grads[k], np.float64).reshape(-1) for k in names])
+        want_rows.append(np.concatenate([flat, [loss * gb, float((y[lo:hi] ** 2).sum())]]))
+        opt.zero_grad()
+        for k, p in zip(names, tp):
+            p.grad = torch.from_numpy(np.asarray(grads[k], np.float64).reshape(p.shape).copy())
+        opt.step()
+    want_p = np.concatenate([p.detach().numpy().reshape(-1) for p in tp])
+    for rank, rows, p in res:
+        for i in range(steps):
+            np.testing.assert_allclose(rows[i], want_rows[i], rtol=0, atol=1e-9, err_msg=f'rank {rank} step {i}')
+        np.testing.assert_allclose(p, want_p, rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(p, res[0][2])                  # replicas bitwise identical
