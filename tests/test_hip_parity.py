@@ -588,6 +588,8 @@ def test_float32_module_like_the_reference(dev):
     (2, (4, 2, 3, 2), 96, 32),           # n = 2 (8 columns per sub-layer)
     (5, (2, 2, 2, 2), 3 * 2304 + 100, 2304),   # one-wave ZYZ kernel (batch beyond 3/4 of the SIMDs)
     (5, (2, 2, 2, 2), 3 * 1024 + 100, 1024),   # two pipelines per workgroup: 256 partial rows, four per row slice
+    (5, (40, 2, 20, 2), 2 * 1024 + 100, 1024), # the headline's 60-block circuit at its batch
+    (5, (40, 2, 20, 2), 2 * 512 + 100, 512),   # ... and at cfg 3's shard: the quad-chain pipeline
 ])
 def test_train_steps_from_one_host_call_equal_the_single_steps_bitwise(nq, net, n_rows, bs):
     """qhea_model_train_steps (one epoch's inner loop from one host call; on block-unrolled shapes the reduce kernel of a
