@@ -160,6 +160,9 @@ __device__ __forceinline__ void prep_layer_body(const Runs& runs, int n, int L, 
         }
     }
     __syncthreads();
+#ifdef QHEA_REDUCE_STAMPS
+    const unsigned long long ps1 = __builtin_amdgcn_s_memtime();
+#endif
     if (j < 2 * n) {                                   // one decomposition per thread, then everybody multiplies phasors
         const int which = j / n, q = j % n;
         const LayerInfo& li = which ? prev : cur;
@@ -190,6 +193,9 @@ __device__ __forceinline__ void prep_layer_body(const Runs& runs, int n, int L, 
         }
     }
     __syncthreads();
+#ifdef QHEA_REDUCE_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 30) printf("  records: decompositions %llu clk (after the sincos barrier)\n", __builtin_amdgcn_s_memtime() - ps1);
+#endif
     char* out = rec + (long)l * kRecBytes;
     if (j < (1 << n)) {
         double2 ph = make_double2(1.0, 0.0);
@@ -728,6 +734,9 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
     __shared__ int dp_failed;
     const int bid = blockIdx.x;
     const DpX* dp = DP ? &dpx : nullptr;
+#ifdef QHEA_REDUCE_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (FUSE) if (bid < nb_w) {           // (block-uniform)
         __shared__ PrepShared psh[kFuseMaxLd + 1];
         __shared__ double newp[kFuseMaxLd * 3 * QHEA_MAX_QUBITS];
@@ -735,6 +744,9 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, accbig, hdr->status != 0, gmap, &adam,
                          gm.off_ans, fp.ld * kw, newp, dp, &dp_failed);
         __syncthreads();
+#ifdef QHEA_REDUCE_STAMPS
+        const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
         const int grp = (int)threadIdx.x >> 6, j = (int)threadIdx.x & 63;
         const int per = 1 + fp.ld, s0 = bid * fp.ld;
         const bool act = grp <= fp.ld;
@@ -742,6 +754,9 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         prep_layer_body(fp.runs, n, fp.L, l, act ? j : -1,
                         [&](int s, int k, int q) { return newp[(s - s0) * 3 * n + k * n + q]; }, fp.rec, fp.srec, fp.gmap,
                         psh[act ? grp : 0]);
+#ifdef QHEA_REDUCE_STAMPS
+        if (threadIdx.x == 0 && (bid == 0 || bid == 30)) printf("reduce block %d: sums+tree+adam %llu clk, records %llu clk\n", bid, st1 - st0, __builtin_amdgcn_s_memtime() - st1);
+#endif
         return;
     }
     // hand-off overrun in the circuit kernel: NaN out, no parameter update.  The word is only USED at the end of each
@@ -812,6 +827,9 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
             grad[gm.off_w[si] + ee] = t1;
             if (adam.p && !skip) { adam_update(adam, gm.off_b[si] + ee, t0); adam_update(adam, gm.off_w[si] + ee, t1); }
         }
+#ifdef QHEA_REDUCE_STAMPS
+        if (threadIdx.x == 0 && bid == nb_w) printf("reduce freq block: %llu clk\n", __builtin_amdgcn_s_memtime() - st0);
+#endif
     } else {
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         for (long b = threadIdx.x; b < B; b += kRedThreads) {

@@ -884,6 +884,13 @@ __device__ __forceinline__ void store_grad_x(double (&gx)[Cfg<N>::KX], int lane,
     if (bs < B && klow < m) grad_x[bs * E + col + klow] = gx[0];
 }
 
+// A result the NEXT launch reads (partial gradient rows, grad_x): stored write-through (`global_store ... sc1`, what a relaxed
+// agent-scope atomic store lowers to) instead of left dirty in this XCD's L2 for the end-of-kernel write-back -- the 6 MB a
+// cfg-2 launch produces then leave the chip while the kernel still runs (-1 % per step at B = 512 and 1024).
+__device__ __forceinline__ void store_through(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // n = 5 (two samples of 32 lanes per wave, KX = 8): the same per-sample sums with the transposing steps in the cheap
 // order of butterfly_sum -- bit 4 by v_permlane16_swap (4 pairs x 3), bits 3 and 2 by bank-masked DPP (2 x 5 + 5), bits
 // 1, 0 as plain pair sums: 33 instructions instead of 55.  The lane with bits (4, 3, 2) = (j0, j1, j2) and bits 1, 0
@@ -915,7 +922,7 @@ __device__ __forceinline__ void store_grad_x5(double (&v)[8], int lane, long wav
     v[0] = pair_sum<1>(v[0]);
     const int j = ((lane >> 4) & 1) | (((lane >> 3) & 1) << 1) | (((lane >> 2) & 1) << 2);
     const long bs = wave * 2 + (lane >> 5);
-    if ((lane & 3) == 0 && bs < B && j < m) grad_x[bs * E + col + j] = v[0];
+    if ((lane & 3) == 0 && bs < B && j < m) store_through(&grad_x[bs * E + col + j], v[0]);
 }
 
 // ---------------------------------------------------------------------------------------

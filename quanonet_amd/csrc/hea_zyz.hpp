@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
         auto store_sums = [&](double (&acc3)[C::KW], int sub) {
             const int vi = butterfly_sum<C::KW>(acc3, lane);
             if (butterfly_owner<C::KW>(lane)) {
-                if constexpr (PIPES == 1) part_w[(long)sub * C::KW + vi] = acc3[0];
+                if constexpr (PIPES == 1) store_through(&part_w[(long)sub * C::KW + vi], acc3[0]);
                 else __hip_atomic_fetch_add(&row_lds[sub * C::KW + vi], acc3[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         };
@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
     if constexpr (PIPES > 1) {
         __syncthreads();                                   // every wave gets here, also after an overrun
         double* __restrict__ row = a.partial + (long)blockIdx.x * a.blk * C::KW;
-        for (int i = (int)threadIdx.x; i < a.blk * C::KW; i += 64 * kZPipeWaves * PIPES) row[i] = row_lds[i];
+        for (int i = (int)threadIdx.x; i < a.blk * C::KW; i += 64 * kZPipeWaves * PIPES) store_through(&row[i], row_lds[i]);
     }
 }
 
@@ -1334,7 +1334,7 @@ __device__ __forceinline__ void zsigma_walk(const ZBwdArgs& a, int lane, int me,
     };
     auto store_sums = [&](double (&acc3)[C::KW], int sub) {
         const int vi = butterfly_sum<C::KW>(acc3, lane);
-        if (butterfly_owner<C::KW>(lane)) part_w[(long)sub * C::KW + vi] = acc3[0];
+        if (butterfly_owner<C::KW>(lane)) store_through(&part_w[(long)sub * C::KW + vi], acc3[0]);
     };
     const int LDr = a.fast_ld, nsteps = a.nblocks * LDr;
     auto draw = [&]() {
