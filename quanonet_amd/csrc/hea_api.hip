@@ -713,6 +713,7 @@ constexpr int kFreqCols = 16, kFreqSlices = kRedThreads / kFreqCols;
 // depend on nothing else: the block's ld sub-layers' and the FOLLOWING chunk's (or the final record's), whose diagonals
 // take this block's last sub-layer through the ring.  The first chunk's record never changes.  No prep launch then.
 struct FusePrep {
+    int nbk;                // circuit blocks per reduce block: 1, or 2 where a block's columns fill half a reduce block (n = 2, ld = 1)
     int ld;                 // 0: off
     int L;                  // layer count (records 0 .. L)
     Runs runs;
@@ -738,19 +739,22 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
     if constexpr (FUSE) if (bid < nb_w) {           // (block-uniform)
-        __shared__ PrepShared psh[kFuseMaxLd + 1];
+        __shared__ PrepShared psh[2 * kFuseMaxLd];          // one per record group: nbk x (ld + 1) <= 4
         __shared__ double newp[kFuseMaxLd * 3 * QHEA_MAX_QUBITS];
         __shared__ double accbig[2 * kRedThreads];
         reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, accbig, hdr->status != 0, gmap, &adam,
-                         gm.off_ans, fp.ld * kw, newp, dp, &dp_failed);
+                         gm.off_ans, fp.nbk * fp.ld * kw, newp, dp, &dp_failed);
         __syncthreads();
 #ifdef QHEA_REDUCE_STAMPS
         const unsigned long long st1 = __builtin_amdgcn_s_memtime();
 #endif
         const int grp = (int)threadIdx.x >> 6, j = (int)threadIdx.x & 63;
-        const int per = 1 + fp.ld, s0 = bid * fp.ld;
-        const bool act = grp <= fp.ld;
-        const int l = act ? (grp < fp.ld ? bid * per + 1 + grp : (bid + 1) * per) : 0;
+        // record groups of 64 threads: for each of the reduce block's nbk circuit blocks, its ld sub-layers' records and the
+        // FOLLOWING chunk's record (whose diagonal takes this block's last sub-layer through the ring)
+        const int per = 1 + fp.ld, s0 = bid * fp.nbk * fp.ld;
+        const bool act = grp < fp.nbk * per;
+        const int cb = bid * fp.nbk + grp / per, g = grp % per;
+        const int l = act ? (g < fp.ld ? cb * per + 1 + g : (cb + 1) * per) : 0;
         prep_layer_body(fp.runs, n, fp.L, l, act ? j : -1,
                         [&](int s, int k, int q) { return newp[(s - s0) * 3 * n + k * n + q]; }, fp.rec, fp.srec, fp.gmap,
                         psh[act ? grp : 0]);
@@ -1227,13 +1231,19 @@ static int model_forward_impl(const qhea_model_desc* desc, int64_t batch, const 
 
 // the reduce kernel can write the next step's records: ZYZ kernels on a block-unrolled shape whose reduce block (ld x kw
 // columns) divides the block size
-static bool model_fuse_eligible(const ModelInfo& mi, const Layout& L) {
+// circuit blocks per reduce block of the fused path, 0 = the shape is not eligible.  A reduce block of 16 or 32 columns adds
+// every column exactly as the plain 16-column blocks do; it must own whole circuit blocks: ld x kw = 16 or 32 columns is one
+// block, 8 columns (n = 2 with one sub-layer per block: the shipped Antideriv Q2 Net5-1-5-1 model) are half a reduce block, so
+// two consecutive circuit blocks share one (an even number of blocks is needed).
+static int model_fuse_blocks(const ModelInfo& mi, const Layout& L) {
     const int ld = zyz_fast_ld(mi.sh.runs, mi.n), kw = padded_3n(mi.n);
-    // (a reduce block of ld x kw = 16 or 32 columns adds every column exactly as the plain 16-column blocks do; n = 2 with
-    //  one sub-layer per block would need two circuit blocks per reduce block: not built)
+    if (!(L.ztri || L.zpacked) || ld < 1 || ld > kFuseMaxLd || mi.sh.blk % ld != 0) return 0;
     const int cols = ld * kw;
-    return (L.ztri || L.zpacked) && ld >= 1 && ld <= kFuseMaxLd && (cols == 16 || cols == 32) && mi.sh.blk % ld == 0;
+    if (cols == 16 || cols == 32) return 1;
+    if (cols == 8 && (mi.sh.blk / ld) % 2 == 0) return 2;
+    return 0;
 }
+static bool model_fuse_eligible(const ModelInfo& mi, const Layout& L) { return model_fuse_blocks(mi, L) != 0; }
 
 // reduce launch of the model-level calls: FUSE = also writes the next step's records, dpx = exchanges with the peer ranks
 static int launch_reduce_model(int nblocks, hipStream_t st, const ModelInfo& mi, int kw, long nwaves, const double* partial,
@@ -1293,10 +1303,11 @@ static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, cons
         if (records_for_next) {
             if (!model_fuse_eligible(mi, M.L) || !adam.p) return QHEA_EINVAL;
             fp.ld = zyz_fast_ld(mi.sh.runs, mi.n);
+            fp.nbk = model_fuse_blocks(mi, M.L);
             fp.L = M.L.zL; fp.runs = mi.sh.runs;
             fp.rec = ws + M.L.off_rec; fp.srec = M.L.zsplit ? ws + M.L.off_srec : nullptr;
             fp.gmap = reinterpret_cast<double*>(ws + M.L.off_gmap);
-            nb_w = (int)(mi.sh.blk / fp.ld);                   // one reduce block per circuit block
+            nb_w = (int)(mi.sh.blk / fp.ld / fp.nbk);          // one reduce block per circuit block (n = 2, ld = 1: per two)
         }
         if (dpx && !dp_blocks_ok(nb_w + nb_x + 1)) return QHEA_EUNSUPPORTED;
         if (!records_ready) {

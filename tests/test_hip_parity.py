@@ -586,6 +586,8 @@ def test_float32_module_like_the_reference(dev):
     (5, (3, 1, 2, 1), 200, 50),          # LD = 1
     (3, (2, 2, 3, 2), 150, 50),          # n = 3 (pad(3n) = 16 columns per sub-layer)
     (2, (4, 2, 3, 2), 96, 32),           # n = 2 (8 columns per sub-layer)
+    (2, (5, 1, 5, 1), 4 * 32 + 7, 32),   # n = 2, ONE sub-layer per block (the shipped Antideriv Q2 model, cfg 1): two circuit blocks per reduce block
+    (2, (3, 1, 2, 1), 4 * 32 + 7, 32),   # ... with an odd number of blocks: not eligible, a prep launch per step
     (5, (2, 2, 2, 2), 3 * 2304 + 100, 2304),   # one-wave ZYZ kernel (batch beyond 3/4 of the SIMDs)
     (5, (2, 2, 2, 2), 3 * 1024 + 100, 1024),   # two pipelines per workgroup: 256 partial rows, four per row slice
     (5, (40, 2, 20, 2), 2 * 1024 + 100, 1024), # the headline's 60-block circuit at its batch
