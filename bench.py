@@ -212,6 +212,37 @@ def secondary_configs(dev, measure_many):
             "train_samples_per_s": epochs * nrows / dt,
             "frac_fp64_vector_step": 22.0 * 32 * 2100 * (nrows * epochs) / dt / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
         del sv
+    # the reference's own training configurations through the same loop (batch 100, Adam 1e-4, scripts/reproduce_benchmarks1.sh:15-21):
+    # the README's default model -- TF-QuanONet Antideriv Q5 Net20-2-10-2, 1000 epochs x 10 000 rows = 10^5 steps, "~80 min on a
+    # server-class CPU" with MindQuantum (README.md:167-178; the only published wall time) -- and the shipped Q2 Net5-1-5-1 model
+    for key, what, nq, net, b_in, anchor in (
+            ('ptsolver_loop_readme_default_q5_net20-2-10-2_batch100', 'README default: TF-QuanONet Antideriv Q=5 Net20-2-10-2, num_points_0 100', 5, [20, 2, 10, 2], 100,
+             {"reference_wall_time": "~80 min (server-class CPU, MindQuantum), README.md:167-178", "reference_steps": 100000}),
+            ('ptsolver_loop_antideriv_q2_net5-1-5-1_batch100', 'shipped checkpoint\'s model: QuanONet Antideriv Q=2 Net5-1-5-1, num_points_0 10', 2, [5, 1, 5, 1], 10, None)):
+        nrows = 10000
+        data = {'train_branch_input': rng.normal(size=(nrows, b_in)), 'train_trunk_input': rng.uniform(size=(nrows, 1)),
+                'train_output': rng.normal(scale=0.5, size=(nrows, 1)),
+                'test_branch_input': rng.normal(size=(64, b_in)), 'test_trunk_input': rng.uniform(size=(64, 1)),
+                'test_output': rng.normal(scale=0.5, size=(64, 1))}
+        cfg = {'model_type': 'QuanONet', 'operator': 'Antideriv', 'num_qubits': nq, 'net_size': net, 'scale_coeff': 0.01,
+               'if_trainable_freq': 'true', 'learning_rate': 1e-4, 'batch_size': 100, 'num_epochs': 8, 'if_save': False,
+               'prefix': tempfile.mkdtemp()}
+        set_random_seed(0)
+        sv = PTSolver(cfg, data, device=dev, log=lambda *a, **k: None)
+        sv.train()                                               # warm-up: 800 steps
+        torch.cuda.synchronize()
+        sv.config['num_epochs'] = 20
+        t0 = time.perf_counter()
+        sv.train()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        steps = 20 * (nrows // 100)
+        out[key] = {"workload": f"PTSolver.train whole loop, {what}, {nrows} resident rows, batch 100", "batch": 100, "steps": steps,
+                    "ms_per_step": 1e3 * dt / steps, "train_samples_per_s": 20 * nrows / dt,
+                    "projected_seconds_for_the_reference_run": 1e5 * dt / steps}
+        if anchor:
+            out[key].update(anchor)
+        del sv
     return out
 
 
