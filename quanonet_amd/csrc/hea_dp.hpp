@@ -73,6 +73,10 @@ __device__ __forceinline__ bool dpx_flags_and_wait(const DpX& x, FlagOf flag_of,
     const int tid = threadIdx.x;
     if (tid == 0) *sh_failed = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: every store above has left this device
+    // (the wait behind the write-back, spelled out: the compiler may drop it where it believes the wave has no vector-memory
+    // operation outstanding -- MI355X_MICROARCH.md, inter-workgroup visibility, "compiler hazard" -- and a flag must never
+    // overtake the data it announces)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid < x.world)
         __hip_atomic_store(flag_of(x.bufs[tid], x.rank), x.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
