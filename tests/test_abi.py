@@ -210,3 +210,11 @@ def test_dp_train_steps_argument_validation_without_gpu(lib):
     assert call(rows=bad_rows) == -1
     assert call(rows=empty_rows) == -2               # an empty shard: QHEA_EUNSUPPORTED, the caller takes the separate exchange
     assert call() == -3                              # everything valid up to the (missing) workspace: nothing was launched
+
+
+def test_clock_probe_argument_validation_without_gpu(lib):
+    lib.qhea_clock_probe.restype = ctypes.c_int
+    lib.qhea_clock_probe.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.qhea_clock_probe(0, 10, ctypes.c_void_p(8), None) == -1
+    assert lib.qhea_clock_probe(4, 0, ctypes.c_void_p(8), None) == -1
+    assert lib.qhea_clock_probe(4, 10, None, None) == -1

@@ -135,3 +135,12 @@ def test_many_training_steps_never_overrun(variant, batch):
             assert torch.isfinite(flat).all(), i
     finally:
         _lib.set_backward_variant('auto')
+
+
+@pytest.mark.gpu
+def test_clock_probe_reports_a_plausible_shader_clock():
+    """qhea_clock_probe (bench.py's `device_clock`): shader-clock ticks against the 100 MHz counter inside a kernel."""
+    import torch
+    from quanonet_amd import _lib
+    med, lo, hi = _lib.clock_probe(torch.device('cuda:0'), n_workgroups=256, iters=50000)
+    assert 500.0 < lo <= med <= hi < 4000.0, (med, lo, hi)
