@@ -634,7 +634,16 @@ class PTSolver:
             return idx
         return torch.as_tensor(np.random.permutation(n), device=self.device)
 
+    def is_completed(self):
+        """Whether this run's directory already holds a metric.json -- the reference's "experiment already completed" test
+        (utils/logger.py:182-185), on which its train() ends the process (solvers/solver_pt.py:192-194)."""
+        return os.path.exists(os.path.join(self.out_dir, 'metric.json'))
+
     def train(self):
+        if self.config.get('skip_completed', False) and self.is_completed():
+            # the reference calls sys.exit(0) here; a library returns instead (the launcher decides what to do with None)
+            self.log("Experiment already completed (metric.json exists): training skipped.")
+            return None
         n = self.train_output.shape[0]
         bs = min(int(self.config.get('batch_size', 100)), n)
         epochs = int(self.config['num_epochs'])

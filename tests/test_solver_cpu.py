@@ -215,3 +215,24 @@ def test_lbfgs_is_rejected_like_the_reference():
     model = H.quanonet_with_oracle_layer(N, B_IN, T_IN, NET)
     with pytest.raises(NotImplementedError):            # solvers/solver_pt.py:154-155
         DataParallelTrainer(model, lr=1e-2, fused=False, optimizer='lbfgs')
+
+
+def test_completed_run_is_skipped_like_the_reference(tmp_path):
+    """solvers/solver_pt.py:192-194: a run whose directory already holds metric.json is not trained again (the reference
+    exits the process there; PTSolver.train returns None when config['skip_completed'] is set)."""
+    from quanonet_amd.solver import PTSolver, set_random_seed
+    cfg, data, a, order, seed = H.trajectory_solver_inputs('quanonet_tf', str(tmp_path), skip_completed=True, num_epochs=1)
+    set_random_seed(seed)
+    from quanonet_amd.models import QuanONetPT
+    model = H.quanonet_with_oracle_layer(cfg['num_qubits'], data['train_branch_input'].shape[1], data['train_trunk_input'].shape[1],
+                                         tuple(cfg['net_size']))
+    s = PTSolver(cfg, data, device=torch.device('cpu'), model=model, log=lambda *x, **k: None)
+    assert not s.is_completed()
+    hist = s.train()
+    assert hist is not None and len(hist['loss_train']) == 1
+    s.evaluate(hist)                                   # writes metric.json
+    assert s.is_completed()
+    before = {k: v.clone() for k, v in s.model.state_dict().items()}
+    assert s.train() is None                           # skipped
+    for k, v in s.model.state_dict().items():
+        assert torch.equal(v, before[k])
