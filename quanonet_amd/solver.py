@@ -713,7 +713,7 @@ class PTSolver:
             if epoch % 10 == 0:
                 self.log(f"Epoch {epoch} | MSE: {avg_loss:.6e} | Rel_L2: {avg_rel:.4%}")
         if self.config.get('if_save', True) and self.rank == 0:
-            self._save(os.path.join(self.out_dir, 'final_model.pt'))
+            self._save(os.path.join(self.out_dir, 'final.pt'))                 # logger.py:174-177 + solver_pt.py:266-272: final.pt / final.npz
         return history
 
     # ---- evaluation (solver_pt.py:279-329, utils/metrics.py:6-29) -----------------------------------------

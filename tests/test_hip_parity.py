@@ -469,7 +469,7 @@ def test_ptsolver_end_to_end(dev, tmp_path):
     assert set(m) == {'MSE', 'MAE', 'Max_Error', 'rel_l2'} and np.isfinite(m['rel_l2'])
     out_dir = s.out_dir
     import os, json
-    for f in ('best_model.pt', 'best_model.npz', 'final_model.pt', 'final_model.npz', 'metric.json'):
+    for f in ('best_model.pt', 'best_model.npz', 'final.pt', 'final.npz', 'metric.json'):
         assert os.path.exists(os.path.join(out_dir, f)), f
     z = np.load(os.path.join(out_dir, 'best_model.npz'))
     assert sorted(z.files) == sorted(['bias', 'branch_freq.weights', 'branch_freq.bias', 'trunk_freq.weights',

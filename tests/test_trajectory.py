@@ -41,7 +41,7 @@ def _assert_matches_trace(solver, hist, a, order, tol):
     assert int(np.argmin(hist['loss_train'])) == int(a['best_epoch'])
     for k in order:
         np.testing.assert_allclose(best[k].reshape(-1), a['best.' + k].reshape(-1), rtol=0, atol=tol, err_msg='best ' + k)
-    fin = np.load(os.path.join(solver.out_dir, 'final_model.npz'))
+    fin = np.load(os.path.join(solver.out_dir, 'final.npz'))
     for k in order:
         np.testing.assert_allclose(fin[k].reshape(-1), a['final.' + k].reshape(-1), rtol=0, atol=tol)
 
