@@ -72,21 +72,25 @@ template <class FlagOf>
 __device__ __forceinline__ bool dpx_flags_and_wait(const DpX& x, FlagOf flag_of, int* sh_failed) {
     const int tid = threadIdx.x;
     if (tid == 0) *sh_failed = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: every store above has left this device
-    // (the wait behind the write-back, spelled out: the compiler may drop it where it believes the wave has no vector-memory
-    // operation outstanding -- MI355X_MICROARCH.md, inter-workgroup visibility, "compiler hazard" -- and a flag must never
-    // overtake the data it announces)
+    // Hand-off without cache maintenance.  Every published value is a system-scope atomic store (`global_store ... sc0 sc1`:
+    // written through to the memory it lives in, never left in an L2) and every read of a slot is a system-scope atomic load
+    // (dpx_collect), so neither a write-back nor an invalidate is needed -- MI355X_MICROARCH.md, inter-workgroup visibility:
+    // "{sc0 sc1 stores and loads both sides}" with (a) every storing wave waiting for its stores (`s_waitcnt vmcnt(0)`: the
+    // stores have been acknowledged by the memory they target, the peer's included) and (b) the flag raised only after the
+    // wait of EVERY wave it speaks for -- the workgroup barrier below.  A system-scope release fence here (`buffer_wbl2 sc0
+    // sc1`, every thread of every reduce block, with the kernel's own plain stores dirty in L2) and the acquire after the
+    // wait (`buffer_inv`) cost 30-37 us per step inside the reduce kernel (profiles/r03_dp_loopback.json).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid < x.world)
-        __hip_atomic_store(flag_of(x.bufs[tid], x.rank), x.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(flag_of(x.bufs[tid], x.rank), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     char* own = x.bufs[x.rank];
     DpHeader* hdr = reinterpret_cast<DpHeader*>(own);
     if (tid < x.world) {
         const unsigned long long* f = flag_of(own, tid);
         const long long t0 = wall_clock64();
         int fail = 0;
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < x.seq) {
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < x.seq) {
             if (__hip_atomic_load(&hdr->poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { fail = 2; break; }
             if (wall_clock64() - t0 > x.timeout_ticks) { fail = 1; break; }
             __builtin_amdgcn_s_sleep(8);
@@ -102,8 +106,7 @@ __device__ __forceinline__ bool dpx_flags_and_wait(const DpX& x, FlagOf flag_of,
             __hip_atomic_store(&reinterpret_cast<DpHeader*>(x.bufs[tid])->poison, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return false;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    return true;
+    return true;                                             // (the slots are read with system-scope loads: nothing to invalidate)
 }
 
 // sum over the ranks, in rank order, of element idx (after dpx_flags_and_wait returned true)
