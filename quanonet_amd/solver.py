@@ -444,13 +444,37 @@ class DataParallelTrainer:
             self.dp_exchange_reason = (why + "; calibrated on this step: the exchange inside the reduce kernel did not complete "
                                        "within 250 ms (ranks sharing a GPU?) -> separate kernel, buffers re-created")
             return None
+        p_fused = self.pflat.clone()
+        restore()
         t_sep, failed = timed(False)
+        p_sep = self.pflat.clone()
+        if getattr(self, '_calibration_fault', None) is not None:   # tests: a replica that came out different
+            p_sep[0] += self._calibration_fault
         restore()
         if failed:
             raise _lib.QheaError("data-parallel exchange failed during calibration")
+        # Both trials ran the same steps from the same state, and both add the ranks' numbers in rank order: the parameters
+        # they end on must be BITWISE the same, on every rank.  Checked here because this is the first place the exchange
+        # meets the run's real placement of ranks (separate GPUs, the link between them): if the two forms disagree or
+        # the replicas differ, neither is trusted and every rank keeps the collective library's all-reduce.
+        ref = torch.stack([p_fused, p_sep])
+        self.dist.broadcast(ref, src=0)
+        wrong = torch.tensor([0.0 if (torch.equal(p_fused, p_sep) and torch.equal(ref[0], p_fused)
+                                      and torch.equal(ref[1], p_sep)) else 1.0], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(wrong, op=self.dist.ReduceOp.MAX)
+        if wrong.item() > 0.5:
+            torch.cuda.synchronize(dev)
+            self.peer.close()
+            self.peer = None
+            self.peer_fused = False
+            self.fused_ok = False
+            self.dp_exchange_reason += ("; calibrated on this step: the two forms of the peer exchange did NOT end on bitwise "
+                                        "identical parameters on every rank -> all_reduce (collective library) + Adam launch")
+            return None
         self.peer_fused = t_fused <= t_sep                      # (the same numbers on every rank: one decision)
         self.dp_exchange_reason += (f"; calibrated on this step: {t_fused:.4f} ms inside the reduce kernel, {t_sep:.4f} ms "
-                                    f"as a separate kernel -> " + ("inside the reduce kernel" if self.peer_fused else "separate kernel"))
+                                    f"as a separate kernel, parameters bitwise identical through both and on every rank -> "
+                                    + ("inside the reduce kernel" if self.peer_fused else "separate kernel"))
         return t_fused, t_sep
 
     @property

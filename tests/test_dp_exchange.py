@@ -259,6 +259,54 @@ def test_exchange_inside_the_reduce_kernel_equals_the_separate_exchange_bitwise(
         assert np.isfinite(rows).all() and (rows[:, -2] > 0).all()
 
 
+def _calibrate_worker(rank, world, port, q, fault_rank):
+    dist = _init(rank, world, port)
+    from quanonet_amd.models import QuanONetPT
+    from quanonet_amd.solver import DataParallelTrainer
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(9)
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
+    branch, trunk, y = t(rng.normal(size=(48, 7))), t(rng.uniform(size=(48, 2))), t(rng.normal(size=(48, 1)))
+    torch.manual_seed(3)
+    tr = DataParallelTrainer(QuanONetPT(5, 7, 2, (3, 2, 2, 2), scale_coeff=0.1, if_trainable_freq=True).double().to(dev),
+                             lr=1e-2, world_size=world, dist=dist)
+    assert tr.peer is not None, tr.dp_exchange_reason
+    tr.train_step(branch, trunk, y)                              # a state with non-zero Adam moments
+    torch.cuda.synchronize()
+    before = (tr.pflat.clone(), tr.optimizer.exp_avg.clone(), tr.optimizer.exp_avg_sq.clone(), tr.optimizer.t)
+    if rank == fault_rank:
+        tr._calibration_fault = 1e-13
+    got = tr.calibrate_exchange(branch, trunk, y, steps=3)
+    torch.cuda.synchronize()
+    restored = (torch.equal(before[0], tr.pflat) and torch.equal(before[1], tr.optimizer.exp_avg)
+                and torch.equal(before[2], tr.optimizer.exp_avg_sq) and before[3] == tr.optimizer.t)
+    tr.train_step(branch, trunk, y)                              # the run goes on through whatever was kept
+    torch.cuda.synchronize()
+    tr.check_status()
+    q.put((rank, got is not None, tr.peer is not None, restored, tr.dp_exchange_reason, tr.pflat.cpu().numpy()))
+    dist.barrier()
+    if tr.peer is not None:
+        tr.peer.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('fault_rank', [-1, 1])
+def test_calibration_checks_both_forms_bitwise_and_falls_back_to_the_collective(fault_rank):
+    """calibrate_exchange runs the same steps through both forms of the peer exchange: they must end on bitwise identical
+    parameters on every rank (reason string says so, state restored); a rank whose replica differs by one bit's worth
+    sends EVERY rank to the all-reduce."""
+    res = _spawn(_calibrate_worker, 2, extra=(fault_rank,))
+    for rank, chose, has_peer, restored, reason, p in res:
+        assert restored, rank
+        if fault_rank < 0:
+            assert has_peer and 'bitwise identical' in reason, reason
+            # (with two ranks on ONE device the fused trial may also time out under its short bound: then no choice was made)
+            assert chose or 'did not complete' in reason
+        else:
+            assert not chose and not has_peer and 'did NOT end on bitwise identical' in reason, reason
+        np.testing.assert_array_equal(p, res[0][5])
+
+
 def _fused_timeout_worker(rank, world, port, q):
     """The fused step with a missing peer: every block of rank 0's reduce kernel gives up, nothing is updated, the late rank
     fails as well."""
