@@ -86,16 +86,22 @@ __device__ inline GateZ gate_zyz(const double2& ha, const double2& hb, const dou
     const double m10r = cb * sa, m10i = sb * sa, m11r = cb * ca, m11i = sb * ca;
     const double Ar = cc * m00r - sc * m10r, Ai = cc * m00i - sc * m10i;
     const double Br = cc * m01r - sc * m11r, Bi = cc * m01i - sc * m11i;
-    const double nA = sqrt(Ar * Ar + Ai * Ai), nB = sqrt(Br * Br + Bi * Bi);
-    const double r = sqrt(nA * nA + nB * nB);
+    // moduli and phasors through reciprocal square roots (3 rsqrt instead of 4 sqrt + 7 divisions in a row: this function is
+    // on the critical path of the reduce kernel that writes the next step's records).  |A|^2 + |B|^2 = 1 up to rounding (the
+    // matrix is a product of three rotations), so cos(theta/2) = |A|, sin(theta/2) = |B| need no further normalisation.
+    const double a2 = Ar * Ar + Ai * Ai, b2 = Br * Br + Bi * Bi;
+    const double ia = rsqrt(a2), ib = rsqrt(b2);
     GateZ g;
-    g.c = nA / r; g.s = nB / r;
-    const double2 p = nA > 0.0 ? make_double2(Ar / nA, Ai / nA) : make_double2(1.0, 0.0);
-    const double2 m = nB > 0.0 ? make_double2(-Br / nB, -Bi / nB) : make_double2(1.0, 0.0);
+    g.c = a2 > 0.0 ? a2 * ia : 0.0; g.s = b2 > 0.0 ? b2 * ib : 0.0;
+    const double2 p = a2 > 0.0 ? make_double2(Ar * ia, Ai * ia) : make_double2(1.0, 0.0);
+    const double2 m = b2 > 0.0 ? make_double2(-Br * ib, -Bi * ib) : make_double2(1.0, 0.0);
     const double2 z = cmul(p, m);
+    // u = sqrt(z) on the unit circle: with t = (1 + |Re z|) / 2 >= 1/2, the larger component is sqrt(t), the other Im z / (2 sqrt(t))
+    const double t = 0.5 * (1.0 + fabs(z.x)), it = rsqrt(t);
+    const double big = t * it, small = 0.5 * z.y * it;
     double2 u;
-    if (z.x >= 0.0) { u.x = sqrt(0.5 * (1.0 + z.x)); u.y = z.y / (2.0 * u.x); }
-    else            { u.y = copysign(sqrt(0.5 * (1.0 - z.x)), z.y); u.x = z.y / (2.0 * u.y); }
+    if (z.x >= 0.0) { u.x = big; u.y = small; }
+    else            { u.y = copysign(big, z.y); u.x = fabs(small); }
     g.u = u;
     g.v = cmul(p, cconj(u));
     g.cosb = cb * cb - sb * sb; g.sinb = 2.0 * sb * cb;
@@ -145,11 +151,13 @@ struct PrepShared {
 // Record of layer l by a group of 64 threads (j = index within the group; threads of the block outside every group pass
 // j >= 64 and only join the two barriers).  wfetch(s, k, q) = ansatz angle w[s, k, q]: from global memory in
 // prep_zyz_kernel, from the block's freshly updated values where the reduce kernel writes the next step's records.
+// cur / prev = what layers l and l - 1 are (decode_layer(l < L ? l : -1), decode_layer(l - 1); the reduce kernel knows them
+// from its block index and skips the run table's integer divisions).
 template <class F>
-__device__ __forceinline__ void prep_layer_body(const Runs& runs, int n, int L, int l, int j, F wfetch, char* __restrict__ rec,
-                                                char* __restrict__ srec, double* __restrict__ gmap, PrepShared& sh) {
+__device__ __forceinline__ void prep_layer_body(const LayerInfo& cur, const LayerInfo& prev, int n, int l, int j, F wfetch,
+                                                char* __restrict__ rec, char* __restrict__ srec, double* __restrict__ gmap,
+                                                PrepShared& sh) {
     if (j < 0) j = 1 << 30;
-    const LayerInfo cur = decode_layer(runs, n, l < L ? l : -1), prev = decode_layer(runs, n, l - 1);
     if (j < 6 * n) {
         const int which = j / (3 * n), k = (j / n) % 3, q = j % n;
         const LayerInfo& li = which ? prev : cur;
@@ -240,7 +248,8 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
     const int l = blockIdx.x, j = threadIdx.x;
     if (l == 0 && j == 0) header_init(hdr);
     __shared__ PrepShared sh;
-    prep_layer_body(runs, n, L, l, j, [&](int s, int k, int q) { return w[(long)s * 3 * n + k * n + q]; }, rec, srec, gmap, sh);
+    prep_layer_body(decode_layer(runs, n, l < L ? l : -1), decode_layer(runs, n, l - 1), n, l, j,
+                    [&](int s, int k, int q) { return w[(long)s * 3 * n + k * n + q]; }, rec, srec, gmap, sh);
 }
 
 // Deterministic column sums of a row-major [rows, ncols] matrix: a block owns `cols` consecutive columns
@@ -706,7 +715,9 @@ struct GradMap {                // where each gradient lives in the flat output
 // Roles by block index: [0, nb_w) ansatz gradients from the (X,Y,Z) partials; [nb_w, nb_w+nb_x)
 // frequency-layer gradients from grad_x (16 columns x 64 row slices per block); last block: bias gradient,
 // sse, sum y^2.
-constexpr int kFreqCols = 16, kFreqSlices = kRedThreads / kFreqCols;
+// (8 columns = 64 B per row: a frequency block is bound by what ONE CU can pull -- its columns of grad_x and of the inputs over
+// all B rows -- and it was the reduce kernel's longest block at 16 columns once the ansatz blocks' records got cheaper)
+constexpr int kFreqCols = 8, kFreqSlices = kRedThreads / kFreqCols, kFreqStage = 8;
 // Records of the NEXT training step written by this one's reduce kernel (qhea_model_train_steps, block-unrolled shapes:
 // every block = one full RX chunk + ld sub-layers).  One reduce block then owns a whole circuit block -- ld x kw columns,
 // its ld sub-layers' angles and Adam state -- and, once it has updated them, three 64-thread groups write the records that
@@ -755,7 +766,12 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         const bool act = grp < fp.nbk * per;
         const int cb = bid * fp.nbk + grp / per, g = grp % per;
         const int l = act ? (g < fp.ld ? cb * per + 1 + g : (cb + 1) * per) : 0;
-        prep_layer_body(fp.runs, n, fp.L, l, act ? j : -1,
+        // (block-unrolled shapes, zyz_fast_ld: layer cb * per is circuit block cb's full RX chunk, the ld layers after it its
+        // sub-layers cb * ld ..; record L, after the last sub-layer, has no layer of its own)
+        const LayerInfo none{2, 0, 0}, chunk{0, 0, n};
+        const LayerInfo cur = !act ? chunk : g < fp.ld ? LayerInfo{1, cb * fp.ld + g, 0} : (l < fp.L ? chunk : none);
+        const LayerInfo prev = !act ? none : g == 0 ? chunk : LayerInfo{1, cb * fp.ld + g - 1, 0};
+        prep_layer_body(cur, prev, n, l, act ? j : -1,
                         [&](int s, int k, int q) { return newp[(s - s0) * 3 * n + k * n + q]; }, fp.rec, fp.srec, fp.gmap,
                         psh[act ? grp : 0]);
 #ifdef QHEA_REDUCE_STAMPS
@@ -810,11 +826,18 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         }
         acc[slice * kFreqCols + j] = s0; acc2[slice * kFreqCols + j] = s1;
         __syncthreads();
+        // slices combined in two fixed-order stages (kFreqStage interleaved groups, then those), as reduce_xyz_block does
+        double u0 = 0.0, u1 = 0.0;
+        if (slice < kFreqStage)
+            for (int i = slice; i < kFreqSlices; i += kFreqStage) { u0 += acc[i * kFreqCols + j]; u1 += acc2[i * kFreqCols + j]; }
+        __syncthreads();
+        if (slice < kFreqStage) { acc[slice * kFreqCols + j] = u0; acc2[slice * kFreqCols + j] = u1; }
+        __syncthreads();
         const bool mine = slice == 0 && e < E && gm.off_w[si] >= 0;
         double t0 = 0.0, t1 = 0.0;
         bool skip = status != 0;
         if (mine) {
-            for (int i = 0; i < kFreqSlices; ++i) { t0 += acc[i * kFreqCols + j]; t1 += acc2[i * kFreqCols + j]; }
+            for (int i = 0; i < kFreqStage; ++i) { t0 += acc[i * kFreqCols + j]; t1 += acc2[i * kFreqCols + j]; }
             if (skip) t0 = t1 = kNaN;
         }
         if constexpr (DP) {
