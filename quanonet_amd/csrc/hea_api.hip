@@ -70,17 +70,31 @@ __global__ void prep_kernel(int n, int blk, const double* __restrict__ w, double
 // A vanishing |A| or |B| leaves one phasor free: any choice reproduces the matrix, because the phasor only ever
 // multiplies the vanishing modulus.
 // ---------------------------------------------------------------------------------------
+// Diagnostic build (-DQHEA_REDUCE_STAMPS, scripts/exp/reduce_stamps.py): thread 0 of reduce block 30 notes the shader clock at
+// the phases of the reduce kernel and prints the differences at its end.
+#ifdef QHEA_REDUCE_STAMPS
+__device__ unsigned long long qhea_stamps[16];
+#define QHEA_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 30) qhea_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QHEA_STAMP(i) do {} while (0)
+#endif
 struct GateZ {
     double c, s;        // cos(theta/2), sin(theta/2) >= 0
     double2 u, v;       // e^{-i alpha/2}, e^{-i beta/2}
     double cosb, sinb, cosc, sinc;      // of the FULL angles b = w[s,1,q], c = w[s,2,q] (gradient map of the reduce kernel)
 };
+// (The prep / reduce code below is inlined into several kernels whose results are compared BITWISE -- records written by
+// prep_zyz_kernel or by the reduce kernel, gradients through reduce_kernel or any reduce_model_kernel instantiation -- so it
+// does not leave the choice of fused multiply-adds to the compiler: implicit contraction is off, the FMAs that matter are
+// written out.)
 __device__ __forceinline__ double2 cmul(const double2& a, const double2& b) {
-    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#pragma clang fp contract(off)
+    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
 }
 __device__ __forceinline__ double2 cconj(const double2& a) { return make_double2(a.x, -a.y); }
 // (cos, sin) of the three HALF angles a/2, b/2, c/2 of the gate, computed by three threads (prep_zyz_kernel)
 __device__ inline GateZ gate_zyz(const double2& ha, const double2& hb, const double2& hc) {
+#pragma clang fp contract(off)
     const double ca = ha.x, sa = ha.y, cb = hb.x, sb = hb.y, cc = hc.x, sc = hc.y;
     const double m00r = cb * ca, m00i = -sb * ca, m01r = -cb * sa, m01i = sb * sa;
     const double m10r = cb * sa, m10i = sb * sa, m11r = cb * ca, m11i = sb * ca;
@@ -157,6 +171,7 @@ template <class F>
 __device__ __forceinline__ void prep_layer_body(const LayerInfo& cur, const LayerInfo& prev, int n, int l, int j, F wfetch,
                                                 char* __restrict__ rec, char* __restrict__ srec, double* __restrict__ gmap,
                                                 PrepShared& sh) {
+#pragma clang fp contract(off)
     if (j < 0) j = 1 << 30;
     if (j < 6 * n) {
         const int which = j / (3 * n), k = (j / n) % 3, q = j % n;
@@ -168,9 +183,7 @@ __device__ __forceinline__ void prep_layer_body(const LayerInfo& cur, const Laye
         }
     }
     __syncthreads();
-#ifdef QHEA_REDUCE_STAMPS
-    const unsigned long long ps1 = __builtin_amdgcn_s_memtime();
-#endif
+    QHEA_STAMP(5);
     if (j < 2 * n) {                                   // one decomposition per thread, then everybody multiplies phasors
         const int which = j / n, q = j % n;
         const LayerInfo& li = which ? prev : cur;
@@ -180,7 +193,11 @@ __device__ __forceinline__ void prep_layer_body(const LayerInfo& cur, const Laye
             if (which == 0) {
                 const double2 z = cmul(g.u, g.u);                    // e^{-i alpha}
                 double* gm = gmap + ((long)li.s * n + q) * kGmapDoubles;
-                gm[0] = g.cosb; gm[1] = g.sinb; gm[2] = g.cosc; gm[3] = g.sinc; gm[4] = z.x; gm[5] = -z.y;
+                // (everything this body writes is read by the NEXT launch: write-through stores, nothing left dirty in L2 for the
+                // end-of-kernel write-back -- which the next launch waits for)
+                store_through(reinterpret_cast<double2*>(gm), make_double2(g.cosb, g.sinb));
+                store_through(reinterpret_cast<double2*>(gm) + 1, make_double2(g.cosc, g.sinc));
+                store_through(reinterpret_cast<double2*>(gm) + 2, make_double2(z.x, -z.y));
                 // Sub-layer right after a full RX chunk: the chunk's gradients are read off THIS sub-layer's inner
                 // products (hea_zyz.hpp, bwd_ztri_kernel).  Between the two points lies W = prod_q RY(theta_q) RZ(beta_q),
                 // so Im<lam|X_q|psi> there = n . (X, Y, Z)_q here with n the axis of RY RZ X RZ^-1 RY^-1 =
@@ -191,19 +208,17 @@ __device__ __forceinline__ void prep_layer_body(const LayerInfo& cur, const Laye
                     const double2 zb = cmul(g.v, g.v);               // e^{-i beta}
                     const double cb = zb.x, sb = -zb.y, ct = g.c * g.c - g.s * g.s, st = 2.0 * g.c * g.s;
                     double* em = reinterpret_cast<double*>(rec + (long)(l - 1) * kRecBytes + kRecRy) + 3 * q;
-                    em[0] = cb * ct; em[1] = sb; em[2] = -cb * st;
+                    store_through(em, cb * ct); store_through(em + 1, sb); store_through(em + 2, -cb * st);
                     if (srec) {     // ... and in its split record, for the chains that walk back in the split layout (bwd_zquad_kernel)
                         double* es = reinterpret_cast<double*>(srec + (long)(l - 1) * kRecBytes + kSRecRy) + 3 * q;
-                        es[0] = cb * ct; es[1] = sb; es[2] = -cb * st;
+                        store_through(es, cb * ct); store_through(es + 1, sb); store_through(es + 2, -cb * st);
                     }
                 }
             }
         }
     }
     __syncthreads();
-#ifdef QHEA_REDUCE_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x == 30) printf("  records: decompositions %llu clk (after the sincos barrier)\n", __builtin_amdgcn_s_memtime() - ps1);
-#endif
+    QHEA_STAMP(6);
     char* out = rec + (long)l * kRecBytes;
     if (j < (1 << n)) {
         double2 ph = make_double2(1.0, 0.0);
@@ -219,7 +234,7 @@ __device__ __forceinline__ void prep_layer_body(const LayerInfo& cur, const Laye
         const bool one = (j >> 4) & 1;
         if (n == 5 && cur.kind == 0 && cur.m == 5) ph = cmul(ph, make_double2(kR, one ? kR : -kR));
         if (n == 5 && prev.kind == 0 && prev.m == 5) ph = cmul(ph, make_double2(kR, one ? -kR : kR));
-        reinterpret_cast<double2*>(out)[j] = ph;
+        store_through(reinterpret_cast<double2*>(out) + j, ph);
         if (srec) {     // split records (n = 5, hea_zyz.hpp): wires 0..3 of a full RX chunk run as RZ(-pi/2) RY RZ(pi/2) too
             for (int q = 0; q < 4; ++q) {
                 const bool b1 = (j >> q) & 1;
@@ -227,16 +242,16 @@ __device__ __forceinline__ void prep_layer_body(const LayerInfo& cur, const Laye
                 if (prev.kind == 0 && prev.m == 5) ph = cmul(ph, make_double2(kR, b1 ? -kR : kR));
             }
             double* d = reinterpret_cast<double*>(srec + (long)l * kRecBytes + j * 24);
-            d[0] = -ph.y; d[1] = ph.x; d[2] = ph.y;
+            store_through(d, -ph.y); store_through(d + 1, ph.x); store_through(d + 2, ph.y);
         }
     } else if (j >= 32 && j < 32 + 2 * n) {
         const int q = (j - 32) >> 1, var = (j - 32) & 1;
         if (cur.kind == 1) {    // (an RX chunk's record keeps this part for the next sub-layer's axes, written by ITS block)
             double2 e = make_double2(sh.gz[0][q].c, var ? sh.gz[0][q].s : -sh.gz[0][q].s);
-            *reinterpret_cast<double2*>(out + kRecRy + q * 32 + var * 16) = e;
+            store_through(reinterpret_cast<double2*>(out + kRecRy + q * 32 + var * 16), e);
             if (srec) {     // wire 4: the swap form's variants (c, -s) / (s, c)
                 if (q == 4 && var == 1) e = make_double2(sh.gz[0][q].s, sh.gz[0][q].c);
-                *reinterpret_cast<double2*>(srec + (long)l * kRecBytes + kSRecRy + q * 32 + var * 16) = e;
+                store_through(reinterpret_cast<double2*>(srec + (long)l * kRecBytes + kSRecRy + q * 32 + var * 16), e);
             }
         }
     }
@@ -259,25 +274,31 @@ __global__ __launch_bounds__(64) void prep_zyz_kernel(Runs runs, int n, int L, c
 constexpr int kRedThreads = 1024;
 __host__ __device__ constexpr int red_cols(int kw) { return kw < 16 ? 16 : kw; }
 
-__device__ __forceinline__ double slice_sum(const double* __restrict__ p, long rows, long stride_rows,
-                                            int slice, int nslices) {
-    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// Rows slice, slice + nslices, ... of TWO adjacent columns (16-byte loads: half the vector-memory instructions of a
+// column per thread -- at B = 1024 the sums are bound by the CU's address unit, not by the round trip), each column added in a
+// fixed order: eight interleaved accumulators, then a tree.
+__device__ __forceinline__ double2 slice_sum2(const double2* __restrict__ p, long rows, long stride_rows2 /* in double2 */,
+                                              int slice, int nslices) {
+    double2 a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = make_double2(0.0, 0.0);
     long r = slice;
-    const long step = (long)nslices * stride_rows;
-    const double* q = p + (long)slice * stride_rows;
+    const long step = (long)nslices * stride_rows2;
+    const double2* q = p + (long)slice * stride_rows2;
     for (; r + 7L * nslices < rows; r += 8L * nslices, q += 8 * step) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] += q[i * step];
+        for (int i = 0; i < 8; ++i) { const double2 t = q[i * step]; a[i].x += t.x; a[i].y += t.y; }
     }
     // the last (up to seven) rows of the slice: all loads issued together, then added where a row exists -- the same
     // additions as a row-by-row loop, without a memory round trip per row (B = 1024: 256 rows = four per slice, all here)
-    double t[7];
+    double2 t[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) t[i] = (r + (long)i * nslices < rows) ? q[i * step] : 0.0;
+    for (int i = 0; i < 7; ++i) t[i] = (r + (long)i * nslices < rows) ? q[i * step] : make_double2(0.0, 0.0);
 #pragma unroll
     for (int i = 0; i < 7; ++i)
-        if (r + (long)i * nslices < rows) a[i] += t[i];
-    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        if (r + (long)i * nslices < rows) { a[i].x += t[i].x; a[i].y += t[i].y; }
+    return make_double2(((a[0].x + a[1].x) + (a[2].x + a[3].x)) + ((a[4].x + a[5].x) + (a[6].x + a[7].x)),
+                        ((a[0].y + a[1].y) + (a[2].y + a[3].y)) + ((a[4].y + a[5].y) + (a[6].y + a[7].y)));
 }
 
 // grad_w[s,{0,1,2},q] from the per-wave (X,Y,Z) partial sums (column sums over waves of partial[wave][s][kw]).
@@ -291,35 +312,47 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
                                                  double* newp = nullptr /* LDS [cols_block / kw][3][n]: the block's angles after the update */,
                                                  const DpX* dp = nullptr /* data-parallel step: exchange this block's gradients before the update */,
                                                  int* dp_failed = nullptr /* one int of LDS */) {
-    // cols_block = 2 red_cols(kw) (fused path, two sub-layers per block): every thread sums TWO of the 64 row slices, so that
-    // each column's additions are exactly those of the one-sub-layer blocks (acc then holds 2 kRedThreads values)
+#pragma clang fp contract(off)
+    // cols_block = 2 red_cols(kw) (fused path, two sub-layers per block): 64 row slices of 32 columns, so that each column's
+    // additions are exactly those of the one-sub-layer blocks (acc then holds 2 kRedThreads values).  Every width here is a
+    // power of two (padded_3n): shifts and masks, no integer division in front of the loads.
     const int cols = cols_block ? cols_block : red_cols(kw), nslices = kRedThreads / red_cols(kw);
-    const int j = threadIdx.x % cols, slice = threadIdx.x / cols;
-    const int per_thread = cols / red_cols(kw);            // 1 or 2 slices per thread
-    const long ncols = (long)blk * kw;
-    const long v = (long)bid * cols + j;
+    const int lc = __builtin_ctz(cols), lk = __builtin_ctz(kw);
+    const int tid = (int)threadIdx.x;
+    const int j = tid & (cols - 1), slice = tid >> lc;     // roles in the tree and the finish: column j of the block, stage slice
+    const int ncols = blk * kw;
+    const int v = bid * cols + j;
     // the thread that will finish gate (s, q) fetches what the finish needs first: gradient-map coefficients and the
     // three angles' Adam state travel while the partial rows are being summed
-    const int s_fin = (int)(v / kw), r_fin = (int)(v % kw), q_fin = r_fin / 3;
-    const bool fin = slice == 0 && v < ncols && r_fin < 3 * n && r_fin % 3 == 0;
-    const bool upd = fin && adam && adam->p;
-    double gmv[6] = {1.0, 0.0, 1.0, 0.0, 1.0, 0.0}, ap[3] = {0, 0, 0}, am[3] = {0, 0, 0}, av[3] = {0, 0, 0};
+    const int s_fin = v >> lk, r_fin = v & (kw - 1), q_fin = r_fin / 3;
+    // Gate (s, q)'s three columns X, Y, Z sit in three adjacent lanes: the X lane (`fin`) turns the sums into the gradients of
+    // the gate's three angles, then each of the three lanes (`tri`, role k3) owns ONE angle: its gradient-row entry, its Adam
+    // update (three in parallel instead of three in a row), its entry of newp.
+    const int k3 = r_fin % 3;
+    const bool tri = slice == 0 && v < ncols && r_fin < 3 * n;
+    const bool fin = tri && k3 == 0;
+    const bool upd = tri && adam && adam->p;
+    const long my_idx = adam_base + (long)s_fin * 3 * n + (long)k3 * n + q_fin;     // this lane's angle in the flat vector
+    double gmv[6] = {1.0, 0.0, 1.0, 0.0, 1.0, 0.0}, ap = 0.0, am = 0.0, av = 0.0;
     if (fin && gmap) {
         const double* gm = gmap + ((long)s_fin * n + q_fin) * kGmapDoubles;
 #pragma unroll
         for (int i = 0; i < 6; ++i) gmv[i] = gm[i];
     }
-    if (upd) {
-        const long base = adam_base + (long)s_fin * 3 * n + q_fin;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { ap[i] = adam->p[base + (long)i * n]; am[i] = adam->m[base + (long)i * n]; av[i] = adam->v[base + (long)i * n]; }
+    if (upd) { ap = adam->p[my_idx]; am = adam->m[my_idx]; av = adam->v[my_idx]; }
+    QHEA_STAMP(7);
+    {   // sums: thread = (row slice, column PAIR); the threads beyond nslices slices (cols = red_cols(kw): half of them) idle
+        const int jp = tid & (cols / 2 - 1), sl = tid >> (lc - 1), vp = bid * cols + 2 * jp;
+        if (sl < nslices) {
+            double2 r = make_double2(0.0, 0.0);
+            if (vp < ncols)
+                r = slice_sum2(reinterpret_cast<const double2*>(partial + vp), nwaves, ncols / 2, sl, nslices);
+            *reinterpret_cast<double2*>(acc + sl * cols + 2 * jp) = r;
+        }
     }
-    acc[slice * cols + j] = v < ncols ? slice_sum(partial + v, nwaves, ncols, slice, nslices) : 0.0;
-    if (per_thread == 2) {
-        const int s2 = slice + nslices / 2;
-        acc[s2 * cols + j] = v < ncols ? slice_sum(partial + v, nwaves, ncols, s2, nslices) : 0.0;
-    }
+    QHEA_STAMP(8);
     __syncthreads();
+    QHEA_STAMP(1);
     // slices are combined in two fixed-order stages (8 interleaved groups, then those 8): a quarter of the serial
     // LDS read chain of a single 64-term loop, and still the same order on every run
     constexpr int kStage = 8;
@@ -336,10 +369,11 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
         acc[j] = t;
     }
     __syncthreads();
+    QHEA_STAMP(2);
     // the thread that finishes gate (s, q): local gradients of its three angles, then -- data-parallel step -- their sum over
     // the ranks (every thread of the block takes part in the flag / wait phase), then the update
     double gc = 0.0, gb = 0.0, ga = 0.0;
-    const int s = (int)(v / kw), q = q_fin;
+    const int s = s_fin, q = q_fin;
     if (fin) {
         double X = acc[j], Y = acc[j + 1];
         const double Z = acc[j + 2];
@@ -358,7 +392,6 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
         gc = Y; gb = cc * Z + sc * X; ga = cb * Y - sb * cc * X + sb * sc * Z;
         if (poisoned) gc = gb = ga = std::numeric_limits<double>::quiet_NaN();   // the circuit kernel reported an overrun
     }
-    bool skip = poisoned;
     if (dp) {           // (block-uniform)
         const long base = adam_base + (long)s * 3 * n;     // index in the flat [gradients | sse | sum y^2] vector
         if (fin) { dpx_publish(*dp, base + 2 * n + q, gc); dpx_publish(*dp, base + n + q, gb); dpx_publish(*dp, base + q, ga); }
@@ -367,25 +400,21 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
         if (fin) {
             if (ok) { gc = dpx_collect(*dp, base + 2 * n + q); gb = dpx_collect(*dp, base + n + q); ga = dpx_collect(*dp, base + q); }
             else gc = gb = ga = std::numeric_limits<double>::quiet_NaN();
-            skip = !(gc == gc && gb == gb && ga == ga);     // some rank's NaN (its pipeline overran) or a failed exchange: no update anywhere
         }
     }
-    if (fin) {
-        double* gs = grad_w + (long)s * 3 * n;
-        gs[2 * n + q] = gc;
-        gs[n + q] = gb;
-        gs[q] = ga;
-        double pn[3] = {ap[0], ap[1], ap[2]};
-        if (upd && !skip) {                  // this thread alone reads and writes the three angles of gate (s, q)
-            const long base = adam_base + (long)s * 3 * n;
-            pn[2] = adam_update_pre(*adam, base + 2 * n + q, gc, ap[2], am[2], av[2]);
-            pn[1] = adam_update_pre(*adam, base + n + q, gb, ap[1], am[1], av[1]);
-            pn[0] = adam_update_pre(*adam, base + q, ga, ap[0], am[0], av[0]);
-        }
-        if (newp) {                          // (only with an update pending: ap holds the current angles)
-            double* np = newp + (long)(s - (int)((long)bid * cols / kw)) * 3 * n;
-            np[q] = pn[0]; np[n + q] = pn[1]; np[2 * n + q] = pn[2];
-        }
+    // hand the three gradients to their lanes (only the X lane read acc[j .. j+2], and it is done with them)
+    if (fin) { acc[j] = ga; acc[j + 1] = gb; acc[j + 2] = gc; }
+    __syncthreads();
+    if (tri) {
+        const int j0 = j - k3;
+        const double g0 = acc[j0], g1 = acc[j0 + 1], g2 = acc[j0 + 2], g = k3 == 0 ? g0 : k3 == 1 ? g1 : g2;
+        // some rank's NaN (its pipeline overran), this rank's, or a failed exchange: no update of the gate anywhere
+        const bool skip = poisoned || !(g0 == g0 && g1 == g1 && g2 == g2);
+        store_through(&grad_w[(long)s * 3 * n + k3 * n + q], g);
+        double pn = ap;
+        if (upd && !skip) pn = adam_update_pre(*adam, my_idx, g, ap, am, av);     // this lane alone reads and writes this angle
+        if (newp)                                // (only with an update pending: ap holds the current angle)
+            newp[(s - ((bid * cols) >> lk)) * 3 * n + k3 * n + q] = pn;
     }
 }
 
@@ -741,11 +770,13 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         long B, int E, EncDesc enc, const double* __restrict__ grad_x, const double* __restrict__ pred,
         const double* __restrict__ y, double inv_bt, GradMap gm, int nb_w, int nb_x, double* __restrict__ grad,
         AdamArgs adam, const WorkspaceHeader* __restrict__ hdr, const double* gmap, FusePrep fp, DpX dpx) {
+#pragma clang fp contract(off)
     __shared__ double acc[kRedThreads];
     __shared__ double acc2[kRedThreads];
     __shared__ int dp_failed;
     const int bid = blockIdx.x;
     const DpX* dp = DP ? &dpx : nullptr;
+    QHEA_STAMP(0);
 #ifdef QHEA_REDUCE_STAMPS
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -755,10 +786,9 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         __shared__ double accbig[2 * kRedThreads];
         reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, accbig, hdr->status != 0, gmap, &adam,
                          gm.off_ans, fp.nbk * fp.ld * kw, newp, dp, &dp_failed);
+        QHEA_STAMP(3);
         __syncthreads();
-#ifdef QHEA_REDUCE_STAMPS
-        const unsigned long long st1 = __builtin_amdgcn_s_memtime();
-#endif
+        QHEA_STAMP(4);
         const int grp = (int)threadIdx.x >> 6, j = (int)threadIdx.x & 63;
         // record groups of 64 threads: for each of the reduce block's nbk circuit blocks, its ld sub-layers' records and the
         // FOLLOWING chunk's record (whose diagonal takes this block's last sub-layer through the ring)
@@ -775,7 +805,12 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
                         [&](int s, int k, int q) { return newp[(s - s0) * 3 * n + k * n + q]; }, fp.rec, fp.srec, fp.gmap,
                         psh[act ? grp : 0]);
 #ifdef QHEA_REDUCE_STAMPS
-        if (threadIdx.x == 0 && (bid == 0 || bid == 30)) printf("reduce block %d: sums+tree+adam %llu clk, records %llu clk\n", bid, st1 - st0, __builtin_amdgcn_s_memtime() - st1);
+        if (threadIdx.x == 0 && bid == 30) {
+            const unsigned long long e = __builtin_amdgcn_s_memtime();
+            const unsigned long long* t = qhea_stamps;
+            printf("reduce block 30: prologue %llu, first slice %llu | loads+slice sums %llu | tree %llu | finish+adam (thread 0) %llu | barrier %llu | sincos %llu | decomposition %llu | phasors+stores %llu | total %llu clk\n",
+                   t[7] - t[0], t[8] - t[7], t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], e - t[6], e - t[0]);
+        }
 #endif
         return;
     }
@@ -850,8 +885,8 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
             }
         }
         if (mine) {
-            grad[gm.off_b[si] + ee] = t0;
-            grad[gm.off_w[si] + ee] = t1;
+            store_through(&grad[gm.off_b[si] + ee], t0);
+            store_through(&grad[gm.off_w[si] + ee], t1);
             if (adam.p && !skip) { adam_update(adam, gm.off_b[si] + ee, t0); adam_update(adam, gm.off_w[si] + ee, t1); }
         }
 #ifdef QHEA_REDUCE_STAMPS
@@ -891,10 +926,10 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
             }
         }
         if (threadIdx.x == 0) {
-            grad[gm.off_sse] = sse;
-            grad[gm.off_sse + 1] = sy2;
+            store_through(&grad[gm.off_sse], sse);
+            store_through(&grad[gm.off_sse + 1], sy2);
             if (gm.off_bias >= 0) {
-                grad[gm.off_bias] = gbias;
+                store_through(&grad[gm.off_bias], gbias);
                 if (adam.p && !skip) adam_update(adam, gm.off_bias, gbias);
             }
         }

@@ -890,6 +890,12 @@ __device__ __forceinline__ void store_grad_x(double (&gx)[Cfg<N>::KX], int lane,
 __device__ __forceinline__ void store_through(double* p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// (16 bytes: one `global_store_dwordx4 ... sc1`; the atomic builtins stop at 8)
+__device__ __forceinline__ void store_through(double2* p, const double2& v) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d x = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+}
 
 // n = 5 (two samples of 32 lanes per wave, KX = 8): the same per-sample sums with the transposing steps in the cheap
 // order of butterfly_sum -- bit 4 by v_permlane16_swap (4 pairs x 3), bits 3 and 2 by bank-masked DPP (2 x 5 + 5), bits
