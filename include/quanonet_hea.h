@@ -295,10 +295,11 @@ int qhea_adam_step(int64_t n, double* params /*DEVICE*/, const double* grads /*D
  * Data-parallel gradient exchange (the reference has no multi-device step -- this replaces the
  * `all_reduce` + `optimizer.step()` pair a DistributedDataParallel port of solvers/solver_pt.py:232-237 would run).
  * Every rank owns ONE exchange buffer of fine-grained device memory that every other rank maps through hipIpc; one
- * one-workgroup kernel per rank and step writes the rank's flat buffer [gradients | sse | sum y^2] into every rank's
- * buffer, waits for the other ranks' contributions to its own, sums them in rank order (bitwise identical on every
- * rank, reproducible) and applies Adam -- no collective-library launch and no separate optimizer launch on the step's
- * critical path.  Set-up (once): qhea_dp_alloc -> qhea_dp_export -> exchange the 64-byte handles by any means
+ * one-workgroup kernel per rank and step writes the rank's flat buffer [gradients | sse | sum y^2] into every other rank's
+ * buffer -- each value as two 8-byte words that carry the exchange's sequence number, so that a value validates itself
+ * and nothing has to be drained or flagged --, polls its own buffer for the other ranks' words, sums in rank order (bitwise
+ * identical on every rank, reproducible) and applies Adam -- no collective-library launch and no separate optimizer launch
+ * on the step's critical path.  Set-up (once): qhea_dp_alloc -> qhea_dp_export -> exchange the 64-byte handles by any means
  * (torch.distributed.all_gather_object) -> qhea_dp_import each peer's.  The library retains nothing: the caller
  * owns the buffer and the mapped pointers and passes them to every call.
  */
@@ -344,7 +345,7 @@ int qhea_dp_status(void* buffer /*DEVICE: this rank's own*/, void* stream);
  * prep + circuit + reduce + exchange.  Bitwise the results of qhea_model_loss_grad + qhea_dp_allreduce_adam.  Replaces the
  * `loss.backward(); all_reduce; optimizer.step()` a DistributedDataParallel port of solvers/solver_pt.py:232-237 would run.
  * Returns QHEA_EUNSUPPORTED -- before anything is launched -- when a shard is empty or the reduce grid would not be
- * resident at once (more blocks than CUs, or than block flags in the buffers): use qhea_model_loss_grad +
+ * resident at once (more blocks than CUs: its blocks wait for their peers' blocks): use qhea_model_loss_grad +
  * qhea_dp_allreduce_adam for such a run.  Failure semantics as qhea_dp_allreduce_adam / qhea_dp_status.
  */
 int qhea_model_dp_train_steps(const qhea_model_desc* desc, int64_t n_steps, const int64_t* row_begin /*HOST [n_steps+1]*/,

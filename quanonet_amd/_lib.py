@@ -41,7 +41,7 @@ class ModelDesc(ctypes.Structure):
 
 
 MODEL_QUANONET, MODEL_HEAQNN = 0, 1
-MIN_LIB_VERSION = 430           # 0.4.3: + qhea_model_dp_train_steps (exchange inside the reduce kernel)
+MIN_LIB_VERSION = 440           # 0.4.3: + qhea_model_dp_train_steps (exchange inside the reduce kernel)
 BWD_VARIANTS = {'auto': 0, 'packed': 1, 'pair': 2, 'tri': 3, 'ztri': 4, 'zpacked': 5, 'ztri2': 6, 'zquad': 7}
 PAULI = {'Z': 0, 'X': 1, 'Y': 2}
 

@@ -311,7 +311,9 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
                                                  int cols_block = 0 /* columns per block if not red_cols(kw) */,
                                                  double* newp = nullptr /* LDS [cols_block / kw][3][n]: the block's angles after the update */,
                                                  const DpX* dp = nullptr /* data-parallel step: exchange this block's gradients before the update */,
-                                                 int* dp_failed = nullptr /* one int of LDS */) {
+                                                 int* dp_failed = nullptr /* one int of LDS */,
+                                                 double* dp_loc = nullptr /* LDS [kDpBlockValues] */,
+                                                 double* dp_xch = nullptr /* LDS [kDpBlockValues * QHEA_DP_MAX_RANKS] */) {
 #pragma clang fp contract(off)
     // cols_block = 2 red_cols(kw) (fused path, two sub-layers per block): 64 row slices of 32 columns, so that each column's
     // additions are exactly those of the one-sub-layer blocks (acc then holds 2 kRedThreads values).  Every width here is a
@@ -393,12 +395,16 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
         if (poisoned) gc = gb = ga = std::numeric_limits<double>::quiet_NaN();   // the circuit kernel reported an overrun
     }
     if (dp) {           // (block-uniform)
-        const long base = adam_base + (long)s * 3 * n;     // index in the flat [gradients | sse | sum y^2] vector
-        if (fin) { dpx_publish(*dp, base + 2 * n + q, gc); dpx_publish(*dp, base + n + q, gb); dpx_publish(*dp, base + q, ga); }
-        const int blk_id = bid;
-        const bool ok = dpx_flags_and_wait(*dp, [blk_id](char* buf, int r) { return dp_bflag(buf, r, blk_id); }, dp_failed);
+        // the block's values in flat order: value i = (s - s_first) * 3n + k * n + q  <->  flat element base + i
+        const int s_first = (bid * cols) >> lk, s_end = s_first + (cols >> lk) < blk ? s_first + (cols >> lk) : blk;
+        const int nvals = (s_end - s_first) * 3 * n, i0 = (s - s_first) * 3 * n + q;
+        const long base = adam_base + (long)s_first * 3 * n;
+        if (tid == 0) *dp_failed = 0;
+        if (fin) { dp_loc[i0] = ga; dp_loc[i0 + n] = gb; dp_loc[i0 + 2 * n] = gc; }
+        __syncthreads();
+        const bool ok = dpx_exchange_block(*dp, nvals, dp_loc, [base](int i) { return base + i; }, dp_xch, dp_failed);
         if (fin) {
-            if (ok) { gc = dpx_collect(*dp, base + 2 * n + q); gb = dpx_collect(*dp, base + n + q); ga = dpx_collect(*dp, base + q); }
+            if (ok) { ga = dpx_sum(*dp, dp_xch, i0); gb = dpx_sum(*dp, dp_xch, i0 + n); gc = dpx_sum(*dp, dp_xch, i0 + 2 * n); }
             else gc = gb = ga = std::numeric_limits<double>::quiet_NaN();
         }
     }
@@ -774,6 +780,15 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
     __shared__ double acc[kRedThreads];
     __shared__ double acc2[kRedThreads];
     __shared__ int dp_failed;
+    double *dp_loc = nullptr, *dp_xch = nullptr;
+    long* dp_idx = nullptr;
+    int* dp_count = nullptr;
+    if constexpr (DP) {
+        __shared__ double loc[kDpBlockValues], xch[kDpBlockValues * QHEA_DP_MAX_RANKS];
+        __shared__ long idx[kDpBlockValues];
+        __shared__ int count;
+        dp_loc = loc; dp_xch = xch; dp_idx = idx; dp_count = &count;
+    }
     const int bid = blockIdx.x;
     const DpX* dp = DP ? &dpx : nullptr;
     QHEA_STAMP(0);
@@ -785,7 +800,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         __shared__ double newp[kFuseMaxLd * 3 * QHEA_MAX_QUBITS];
         __shared__ double accbig[2 * kRedThreads];
         reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, accbig, hdr->status != 0, gmap, &adam,
-                         gm.off_ans, fp.nbk * fp.ld * kw, newp, dp, &dp_failed);
+                         gm.off_ans, fp.nbk * fp.ld * kw, newp, dp, &dp_failed, dp_loc, dp_xch);
         QHEA_STAMP(3);
         __syncthreads();
         QHEA_STAMP(4);
@@ -820,7 +835,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
     const double kNaN = std::numeric_limits<double>::quiet_NaN();
     if (bid < nb_w) {
         reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, status != 0, gmap, &adam, gm.off_ans,
-                         0, nullptr, dp, &dp_failed);
+                         0, nullptr, dp, &dp_failed, dp_loc, dp_xch);
     } else if (bid < nb_w + nb_x) {
         const int j = threadIdx.x % kFreqCols, slice = threadIdx.x / kFreqCols;
         const int e = (bid - nb_w) * kFreqCols + j;
@@ -876,11 +891,20 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
             if (skip) t0 = t1 = kNaN;
         }
         if constexpr (DP) {
-            if (mine) { dpx_publish(dpx, gm.off_b[si] + ee, t0); dpx_publish(dpx, gm.off_w[si] + ee, t1); }
-            const bool ok = dpx_flags_and_wait(dpx, [bid](char* buf, int r) { return dp_bflag(buf, r, bid); }, &dp_failed);
+            // the block's exchanged values, compacted: (bias, weight) gradient of every column of a trainable segment (the
+            // `mine` threads are lanes 0 .. kFreqCols-1 of wave 0)
+            const unsigned long long bal = __ballot(mine);
+            const int pos = __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull));
+            if (threadIdx.x == 0) { dp_failed = 0; *dp_count = 2 * __popcll(bal); }
             if (mine) {
-                t0 = ok ? dpx_collect(dpx, gm.off_b[si] + ee) : kNaN;
-                t1 = ok ? dpx_collect(dpx, gm.off_w[si] + ee) : kNaN;
+                dp_loc[2 * pos] = t0; dp_loc[2 * pos + 1] = t1;
+                dp_idx[2 * pos] = gm.off_b[si] + ee; dp_idx[2 * pos + 1] = gm.off_w[si] + ee;
+            }
+            __syncthreads();
+            const bool ok = dpx_exchange_block(dpx, *dp_count, dp_loc, [dp_idx](int i) { return dp_idx[i]; }, dp_xch, &dp_failed);
+            if (mine) {
+                t0 = ok ? dpx_sum(dpx, dp_xch, 2 * pos) : kNaN;
+                t1 = ok ? dpx_sum(dpx, dp_xch, 2 * pos + 1) : kNaN;
                 skip = !(t0 == t0 && t1 == t1);
             }
         }
@@ -914,14 +938,18 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         bool skip = poisoned;
         if constexpr (DP) {
             if (threadIdx.x == 0) {
-                dpx_publish(dpx, gm.off_sse, sse); dpx_publish(dpx, gm.off_sse + 1, sy2);
-                if (gm.off_bias >= 0) dpx_publish(dpx, gm.off_bias, gbias);
+                dp_failed = 0;
+                dp_loc[0] = sse; dp_idx[0] = gm.off_sse;
+                dp_loc[1] = sy2; dp_idx[1] = gm.off_sse + 1;
+                if (gm.off_bias >= 0) { dp_loc[2] = gbias; dp_idx[2] = gm.off_bias; }
+                *dp_count = gm.off_bias >= 0 ? 3 : 2;
             }
-            const bool ok = dpx_flags_and_wait(dpx, [bid](char* buf, int r) { return dp_bflag(buf, r, bid); }, &dp_failed);
+            __syncthreads();
+            const bool ok = dpx_exchange_block(dpx, *dp_count, dp_loc, [dp_idx](int i) { return dp_idx[i]; }, dp_xch, &dp_failed);
             if (threadIdx.x == 0) {
-                sse = ok ? dpx_collect(dpx, gm.off_sse) : kNaN;
-                sy2 = ok ? dpx_collect(dpx, gm.off_sse + 1) : kNaN;
-                if (gm.off_bias >= 0) gbias = ok ? dpx_collect(dpx, gm.off_bias) : kNaN;
+                sse = ok ? dpx_sum(dpx, dp_xch, 0) : kNaN;
+                sy2 = ok ? dpx_sum(dpx, dp_xch, 1) : kNaN;
+                if (gm.off_bias >= 0) gbias = ok ? dpx_sum(dpx, dp_xch, 2) : kNaN;
                 skip = !(gbias == gbias) || !ok;
             }
         }
@@ -1058,7 +1086,7 @@ using namespace qhea;
 
 extern "C" {
 
-int qhea_version(void) { return 430; }
+int qhea_version(void) { return 440; }
 
 const char* qhea_strerror(int code) {
     switch (code) {
@@ -1323,7 +1351,7 @@ static int launch_reduce_model(int nblocks, hipStream_t st, const ModelInfo& mi,
 
 // a data-parallel reduce launch needs every block resident at once (its blocks wait for the peers' blocks) and a flag
 // per block in the exchange buffers
-static bool dp_blocks_ok(int nblocks) { return nblocks <= kDpMaxBlocks && nblocks <= simd_count() / 4; }
+static bool dp_blocks_ok(int nblocks) { return nblocks <= kDpMaxBlocks && nblocks <= simd_count() / 4; }      // (all resident: blocks wait for their peers)
 
 static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
                                 const double* y, const double* params, const double* ham_diag, double inv_batch_total,

@@ -5,18 +5,18 @@
 // (13-14 us on the device at world size 1 before any link latency, profiles/r02_allreduce_cost_world1_rccl.json) plus
 // a separate Adam launch, on a step of ~100 us.  Here it is ONE one-workgroup kernel per rank:
 //
-//   publish   every rank writes its buffer into slot [parity][rank] of EVERY rank's exchange buffer (peer buffers are
-//             mapped through hipIpc; write-through stores at system scope), drains them, and then
-//             sets flag[rank] = seq in every rank's header (system-scope release);
-//   collect   it waits until the `world` flags in its OWN header have reached seq (system-scope acquire polls with a
-//             wall-clock bound), sums the `world` slots of its own buffer IN RANK ORDER -- every rank adds the same
+//   publish   every rank writes its values into slot [parity][rank] of every OTHER rank's exchange buffer (peer buffers are
+//             mapped through hipIpc): two self-validating 8-byte words per value, each carrying the exchange's sequence
+//             number as a tag (hea_dp.hpp) -- no flag, nothing to drain;
+//   collect   it polls the slots of its OWN buffer until both words of a value carry the tag (all ranks' words of a value
+//             requested together; wall-clock bound), adds the `world` values IN RANK ORDER -- every rank adds the same
 //             numbers in the same order, so the replicas stay bitwise identical and runs are reproducible -- writes
-//             the sums back and applies Adam to the parameters.
+//             the sums and applies Adam to the parameters.
 //
 // Exchange buffers are fine-grained device memory the library allocates (hipExtMallocWithFlags: hipMalloc'ed memory is
 // cached in the owner's L2, which remote writes do not pass through).  Two slot sets alternate with the parity of seq:
-// a rank can be at most one exchange ahead of the slowest rank (its next collect needs everybody's next flag, which a
-// rank only sets after it has finished reading the previous slots), so seq + 1 never overwrites what a peer still reads.
+// a rank can be at most one exchange ahead of the slowest rank (its next collect needs everybody's next words, which a
+// rank only stores after it has finished reading the previous slots), so seq + 1 never overwrites what a peer still reads.
 // A wait that overruns its bound poisons the output with NaN, skips the Adam update and raises an error word that
 // qhea_dp_status reports -- it never computes through a missing contribution -- and it raises the sticky poison word in
 // EVERY rank's header, so that the late rank and every later exchange fail too (hea_dp.hpp).  The buffer layout and the
@@ -45,19 +45,56 @@ struct DpArgs {
 
 __global__ __launch_bounds__(kDpThreads) void dp_exchange_kernel(DpArgs a) {
     const int tid = threadIdx.x;
+    const DpX& x = a.x;
     __shared__ int failed;
-    // ---- publish: this rank's values into slot [parity][rank] of every rank's buffer (own included)
-    for (long i = tid; i < a.n; i += kDpThreads) dpx_publish(a.x, i, a.local[i]);
-    // ---- flags out, then wait for everybody's flag in the own header
-    const bool ok = dpx_flags_and_wait(a.x, [](char* buf, int r) { return &reinterpret_cast<DpHeader*>(buf)->flag[r]; }, &failed);
-    if (!ok) {
-        for (long i = tid; i < a.n; i += kDpThreads) a.out[i] = std::numeric_limits<double>::quiet_NaN();
-        return;
+    if (tid == 0) failed = 0;
+    __syncthreads();
+    // ---- publish: this rank's values into slot [parity][rank] of every other rank's buffer, one (value, peer) pair per thread
+    const long pairs = a.n * x.world;
+    for (long t = tid; t < pairs; t += kDpThreads) {
+        const long i = t / x.world;
+        const int p = (int)(t - i * x.world);
+#ifndef QHEA_DP_LOOPBACK
+        if (p != x.rank)
+#endif
+            dpx_store(x, p, i, a.local[i]);
     }
-    for (long i = tid; i < a.n; i += kDpThreads) {
-        const double s = dpx_collect(a.x, i);                // rank order on every rank: bitwise identical replicas
+    __syncthreads();             // `out` may be `local` (an in-place sum): every value has been read before any is overwritten
+    // ---- collect: a thread owns a value; the words of all ranks are requested together (one round trip when everybody has
+    // published), stragglers are then waited for one by one; the sum runs in rank order
+    const long long t0 = wall_clock64();
+    const unsigned long long tag = dpx_tag(x);
+    const int parity = (int)(x.seq & 1);
+    char* own = x.bufs[x.rank];
+    int fail = 0;
+    for (long i = tid; i < a.n && !fail; i += kDpThreads) {
+        unsigned long long wa[QHEA_DP_MAX_RANKS], wb[QHEA_DP_MAX_RANKS];
+#pragma unroll
+        for (int r = 0; r < QHEA_DP_MAX_RANKS; ++r)
+            if (r < x.world && r != x.rank) {
+                const unsigned long long* w = dp_words(own, parity, x.world, r, x.npad, i);
+                wa[r] = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                wb[r] = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < QHEA_DP_MAX_RANKS; ++r)
+            if (r < x.world) {
+                double v;
+                if (r == x.rank) v = a.local[i];
+                else if ((wa[r] >> 32) == tag && (wb[r] >> 32) == tag)
+                    v = __longlong_as_double((long long)((wa[r] & 0xffffffffull) | (wb[r] << 32)));
+                else v = dpx_load(x, r, i, t0, fail);
+                s += v;
+            }
         a.out[i] = s;
-        if (a.adam.p && i < a.n_adam) adam_update(a.adam, i, s);
+    }
+    // (a value that arrived in the first request was not checked against the poison word: one look before the agreement)
+    if (!fail && __hip_atomic_load(&reinterpret_cast<const DpHeader*>(own)->poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) fail = 1;
+    const bool ok = dpx_agree(x, fail, &failed);
+    for (long i = tid; i < a.n; i += kDpThreads) {
+        if (!ok) { a.out[i] = std::numeric_limits<double>::quiet_NaN(); continue; }
+        if (a.adam.p && i < a.n_adam) adam_update(a.adam, i, a.out[i]);      // (a.out[i]: this thread's own store)
     }
 }
 

@@ -2,16 +2,21 @@
 // exchange kernel (hea_dp.hip) and by the reduce kernel of the data-parallel training step (hea_api.hip), whose blocks
 // exchange their own columns.
 //
-//   [ DpHeader (256 B) | block flags [QHEA_DP_MAX_RANKS][kDpMaxBlocks] u64 | slots [2 parities][world][padded n] f64 ]
+//   [ DpHeader (256 B) | slots [2 parities][world][padded n] of 16 bytes ]
 //
-// A rank publishes a value by storing it into slot [parity of seq][its rank] of EVERY rank's buffer (peer buffers are mapped
-// through hipIpc; write-through stores at system scope) and, once all its stores have left the device, a flag = seq in every
-// rank's buffer: flag[rank] of the header for the one-workgroup kernel, block flag [rank][block] where every reduce block
-// exchanges its own columns.  A collector polls the flags in its OWN buffer and adds the `world` slots in rank order --
-// every rank adds the same numbers in the same order: replicas stay bitwise identical, runs are reproducible.
+// A value travels as TWO self-validating 8-byte words, (low half | tag) and (high half | tag), tag = the exchange's sequence
+// number: a rank publishes a value by storing the two words into slot [parity of seq][its rank] of every OTHER rank's buffer
+// (peer buffers are mapped through hipIpc; 8-byte system-scope stores, each atomic by itself), and a collector polls the
+// slots of its OWN buffer until both words of a slot carry the tag.  No flag, no drain of the stores before a flag, no second
+// round trip for the data after the flag: an exchange is ONE store propagation (the "LL" idea of the collective libraries).
+// The first version -- data stores, `s_waitcnt vmcnt(0)`, a flag per block, poll, then the data loads: three dependent trips
+// through uncached memory -- cost 11 us inside the reduce kernel (profiles/r03_dp_loopback.json).
+// The ranks' values are added in rank order -- every rank adds the same numbers in the same order: replicas stay bitwise
+// identical, runs are reproducible.  Two slot sets alternate with the parity of seq; a rank is at most one exchange ahead of
+// the slowest (its next collect needs everybody's next words, which a rank stores only after it has read the previous slots).
 //
 // Failure is fatal on EVERY rank: a wait that overruns its wall-clock bound sets the sticky `poison` word in
-// every rank's header.  A collector that finds `poison` set -- while it waits or after its flags have arrived -- fails too:
+// every rank's header.  A collector that finds `poison` set -- while it waits or after its words have arrived -- fails too:
 // NaN results, no Adam update, error bit (qhea_dp_status -> QHEA_EEXCHANGE).  The word is never cleared: after one timeout
 // every later exchange on these buffers fails on every rank, so a late rank cannot complete the step the others gave up on
 // and no replica trains on.
@@ -25,27 +30,24 @@
 namespace qhea {
 
 constexpr size_t kDpHeaderBytes = 256;
-constexpr int kDpMaxBlocks = 512;                    // reduce blocks that may exchange per launch
+constexpr int kDpMaxBlocks = 512;                    // reduce blocks that may exchange per launch (they must all be resident)
+constexpr int kDpBlockValues = 64;                   // values one workgroup exchanges per call of dpx_exchange_block
 
 struct DpHeader {
-    unsigned long long flag[QHEA_DP_MAX_RANKS];      // flag[r] = seq of the last one-workgroup exchange rank r has published here
+    unsigned long long reserved[QHEA_DP_MAX_RANKS];
     unsigned int error;                              // bit 0: a collect on this rank failed since the last qhea_dp_status
     unsigned int poison;                             // sticky: some rank's wait overran -- every later exchange fails
 };
 static_assert(sizeof(DpHeader) <= kDpHeaderBytes, "header");
 
 __host__ __device__ inline long dp_padded(long n) { return (n + 1) & ~1L; }
-__host__ __device__ inline size_t dp_slots_offset() {
-    return kDpHeaderBytes + (size_t)QHEA_DP_MAX_RANKS * kDpMaxBlocks * sizeof(unsigned long long);
-}
+__host__ __device__ inline size_t dp_slots_offset() { return kDpHeaderBytes; }
 __host__ __device__ inline size_t dp_bytes(long n, int world) {
-    return dp_slots_offset() + (size_t)2 * world * dp_padded(n) * sizeof(double);
+    return dp_slots_offset() + (size_t)2 * world * dp_padded(n) * 2 * sizeof(unsigned long long);
 }
-__device__ __forceinline__ double* dp_slot(char* buf, int parity, int world, int r, long npad) {
-    return reinterpret_cast<double*>(buf + dp_slots_offset()) + ((long)parity * world + r) * npad;
-}
-__device__ __forceinline__ unsigned long long* dp_bflag(char* buf, int r, int block) {
-    return reinterpret_cast<unsigned long long*>(buf + kDpHeaderBytes) + (long)r * kDpMaxBlocks + block;
+// the two tagged words of element idx in slot [parity][r]
+__device__ __forceinline__ unsigned long long* dp_words(char* buf, int parity, int world, int r, long npad, long idx) {
+    return reinterpret_cast<unsigned long long*>(buf + dp_slots_offset()) + (((long)parity * world + r) * npad + idx) * 2;
 }
 
 // one exchange, as seen by one launch
@@ -56,66 +58,92 @@ struct DpX {
     unsigned long long seq;
     long long timeout_ticks;                         // of wall_clock64() (100 MHz)
 };
+// never 0 (what a fresh buffer holds)
+__device__ __forceinline__ unsigned long long dpx_tag(const DpX& x) { return x.seq % 0xffffffffull + 1ull; }
 
-// this rank's value `v` of element `idx` into every rank's slot (relaxed; dpx_flags_and_wait releases them)
-__device__ __forceinline__ void dpx_publish(const DpX& x, long idx, double v) {
-    const int parity = (int)(x.seq & 1);
-    for (int p = 0; p < x.world; ++p)
-        __hip_atomic_store(dp_slot(x.bufs[p], parity, x.world, x.rank, x.npad) + idx, v, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
+// this rank's value `v` of element `idx` into rank p's buffer
+__device__ __forceinline__ void dpx_store(const DpX& x, int p, long idx, double v) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v), tag = dpx_tag(x) << 32;
+#ifdef QHEA_DP_LOOPBACK     // measurement build (scripts/exp/dp_loopback.py): one process plays every rank
+    for (int r = 0; r < x.world; ++r) {
+        unsigned long long* w = dp_words(x.bufs[p], (int)(x.seq & 1), x.world, r, x.npad, idx);
+        __hip_atomic_store(w, (bits & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(w + 1, (bits >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#else
+    unsigned long long* w = dp_words(x.bufs[p], (int)(x.seq & 1), x.world, x.rank, x.npad, idx);
+    __hip_atomic_store(w, (bits & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(w + 1, (bits >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
 }
 
-// Called by EVERY thread of the workgroup after its dpx_publish calls: drains the stores, raises flag `flag_of(buffer)` = seq
-// in every rank's buffer, waits for the `world` flags in the own buffer.  Returns true when every contribution has
-// arrived; false after a timeout (poison raised everywhere) or when poison was found.  `sh_failed`: one int of LDS.
-template <class FlagOf>
-__device__ __forceinline__ bool dpx_flags_and_wait(const DpX& x, FlagOf flag_of, int* sh_failed) {
-    const int tid = threadIdx.x;
-    if (tid == 0) *sh_failed = 0;
-    // Hand-off without cache maintenance.  Every published value is a system-scope atomic store (`global_store ... sc0 sc1`:
-    // written through to the memory it lives in, never left in an L2) and every read of a slot is a system-scope atomic load
-    // (dpx_collect), so neither a write-back nor an invalidate is needed -- MI355X_MICROARCH.md, inter-workgroup visibility:
-    // "{sc0 sc1 stores and loads both sides}" with (a) every storing wave waiting for its stores (`s_waitcnt vmcnt(0)`: the
-    // stores have been acknowledged by the memory they target, the peer's included) and (b) the flag raised only after the
-    // wait of EVERY wave it speaks for -- the workgroup barrier below.  A system-scope release fence here (`buffer_wbl2 sc0
-    // sc1`, every thread of every reduce block, with the kernel's own plain stores dirty in L2) and the acquire after the
-    // wait (`buffer_inv`) cost 30-37 us per step inside the reduce kernel (profiles/r03_dp_loopback.json).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid < x.world)
-        __hip_atomic_store(flag_of(x.bufs[tid], x.rank), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// rank r's value of element idx from the OWN buffer: polls until both words carry this exchange's tag.  fail: 0 arrived,
+// 1 poison found, 2 the wait overran (t0 = wall_clock64() at the start of the caller's waiting)
+__device__ __forceinline__ double dpx_load(const DpX& x, int r, long idx, long long t0, int& fail) {
     char* own = x.bufs[x.rank];
-    DpHeader* hdr = reinterpret_cast<DpHeader*>(own);
-    if (tid < x.world) {
-        const unsigned long long* f = flag_of(own, tid);
-        const long long t0 = wall_clock64();
-        int fail = 0;
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < x.seq) {
-            if (__hip_atomic_load(&hdr->poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { fail = 2; break; }
-            if (wall_clock64() - t0 > x.timeout_ticks) { fail = 1; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        if (!fail && __hip_atomic_load(&hdr->poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) fail = 2;
-        if (fail) __hip_atomic_fetch_max(sh_failed, fail == 1 ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const DpHeader* hdr = reinterpret_cast<const DpHeader*>(own);
+    const unsigned long long* w = dp_words(own, (int)(x.seq & 1), x.world, r, x.npad, idx);
+    const unsigned long long tag = dpx_tag(x);
+    for (;;) {
+        const unsigned long long a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long b = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (the poison word travels with the data words, not after them: a rank that arrives late -- its peers gave up a whole
+        // timeout ago -- sees it in the same round trip that brings the words)
+        if (__hip_atomic_load(&hdr->poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { fail = 1; break; }
+        if ((a >> 32) == tag && (b >> 32) == tag)
+            return __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+        if (wall_clock64() - t0 > x.timeout_ticks) { fail = 2; break; }
+        __builtin_amdgcn_s_sleep(2);
     }
+    return std::numeric_limits<double>::quiet_NaN();
+}
+
+// End of a workgroup's exchange: the threads that polled pass what they saw (`fail` of dpx_load); every thread learns the
+// workgroup's outcome.  A timeout raises the poison word in every rank's header.  One barrier; `sh_failed`: one int of LDS,
+// zeroed by the caller before a barrier that precedes this call.
+__device__ __forceinline__ bool dpx_agree(const DpX& x, int fail, int* sh_failed) {
+    DpHeader* hdr = reinterpret_cast<DpHeader*>(x.bufs[x.rank]);
+    if (fail) __hip_atomic_fetch_max(sh_failed, fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
     const int failed = *sh_failed;
     if (failed) {
+        const int tid = threadIdx.x;
         if (tid == 0) atomicOr(&hdr->error, 1u);
         if (failed == 2 && tid < x.world)                    // own wait overran: nobody may complete this or any later exchange
             __hip_atomic_store(&reinterpret_cast<DpHeader*>(x.bufs[tid])->poison, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return false;
     }
-    return true;                                             // (the slots are read with system-scope loads: nothing to invalidate)
+    return true;
 }
 
-// sum over the ranks, in rank order, of element idx (after dpx_flags_and_wait returned true)
-__device__ __forceinline__ double dpx_collect(const DpX& x, long idx) {
-    char* own = x.bufs[x.rank];
-    const int parity = (int)(x.seq & 1);
+// A workgroup exchanges `count` <= kDpBlockValues values, one thread per (value, rank) pair.  local[i] (LDS, visible to the
+// workgroup: the caller has passed a barrier since it was written and since *sh_failed was zeroed) = this rank's value of flat
+// element idx_of(i); on return xch[i * world + r] (LDS) = rank r's.  Returns false on failure (see the header).
+template <class IdxOf>
+__device__ __forceinline__ bool dpx_exchange_block(const DpX& x, int count, const double* local, IdxOf idx_of, double* xch,
+                                                   int* sh_failed) {
+    const int pairs = count * x.world, nthreads = blockDim.x;
+    for (int t = threadIdx.x; t < pairs; t += nthreads) {
+        const int i = t / x.world, p = t - i * x.world;
+        const double v = local[i];
+        if (p == x.rank) xch[t] = v;
+#ifndef QHEA_DP_LOOPBACK
+        else
+#endif
+            dpx_store(x, p, idx_of(i), v);
+    }
+    const long long t0 = wall_clock64();
+    int fail = 0;
+    for (int t = threadIdx.x; t < pairs && !fail; t += nthreads) {
+        const int i = t / x.world, r = t - i * x.world;
+        if (r != x.rank) xch[t] = dpx_load(x, r, idx_of(i), t0, fail);
+    }
+    return dpx_agree(x, fail, sh_failed);
+}
+// sum over the ranks, in rank order, of value i (after dpx_exchange_block returned true)
+__device__ __forceinline__ double dpx_sum(const DpX& x, const double* xch, int i) {
     double s = 0.0;
-    for (int r = 0; r < x.world; ++r)
-        s += __hip_atomic_load(dp_slot(own, parity, x.world, r, x.npad) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int r = 0; r < x.world; ++r) s += xch[i * x.world + r];
     return s;
 }
 

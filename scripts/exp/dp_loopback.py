@@ -1,11 +1,14 @@
 """On-device cost of the data-parallel exchange MECHANISM, without a second rank's kernels competing for the GPU (the only
 multi-rank runs possible on a one-GPU box share the device, and there the waiting blocks of one rank take compute units from the
-other's circuit kernel -- DESIGN.md section 8).  One process, world = 2: rank 0 is the trainer; "rank 1" is a second exchange
-buffer in the same process whose flags were raised once, far into the future, from the host, and whose slots hold zeros.  Every
-block of rank 0's reduce kernel then does all of a real exchange's work -- stores into BOTH buffers, the system-scope release,
-its flag in both headers, the poll, the rank-order sum of two slots -- and finds its peer's contribution already there.  The step
-time against the single-device step is what the mechanism costs on the device; what a real peer adds on top is the xGMI hop
-and the skew between the ranks.  Usage: python scripts/exp/dp_loopback.py"""
+other's circuit kernel -- DESIGN.md section 8).  One process, world = 2, with a library built with -DQHEA_DP_LOOPBACK (hea_dp.hpp:
+a publisher stores its tagged words under EVERY rank's slot of both buffers, so that "rank 1"'s contribution -- a copy of rank 0's --
+is found by the poll): every block of rank 0's reduce kernel does all of a real exchange's work (the stores into both buffers,
+the poll of the peer's slots in its own, the rank-order sum) with no second rank on the GPU.  The step time against the
+single-device step is what the mechanism costs on the device; what a real peer adds on top is the xGMI hop and the skew between
+the ranks.  (The sums are then twice the local gradients: timing only.)
+Usage: make -C quanonet_amd/csrc QUBITS="2 5" SUBSET="-D'QHEA_SUBSET(X)=X(2) X(5)' -D'QHEA_ZSUBSET(X)=X(2) X(5)' -DQHEA_DP_LOOPBACK" \
+            OBJDIR=../../build/obj_loop TARGET=../../scripts/exp/libq_loop.so all
+       QHEA_LIB=scripts/exp/libq_loop.so python scripts/exp/dp_loopback.py"""
 import ctypes, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -14,8 +17,6 @@ from quanonet_amd.models import QuanONetPT
 from quanonet_amd.solver import DataParallelTrainer
 
 dev = torch.device('cuda', 0)
-hip = ctypes.CDLL('libamdhip64.so')
-HEADER, MAX_RANKS, MAX_BLOCKS = 256, 16, 512
 
 
 def timeit(fn, reps=25, inner=5, per=8):
@@ -37,13 +38,6 @@ for batch in (100, 512, 1024):
     n_values = tr.numel + 2
     own = _lib.dp_alloc(n_values, 2, dev)
     peer = _lib.dp_alloc(n_values, 2, dev)
-    big = np.full(MAX_RANKS * MAX_BLOCKS, 1 << 40, dtype=np.uint64)          # every block flag of every rank, in both buffers
-    hdr = np.full(MAX_RANKS, 1 << 40, dtype=np.uint64)                        # ... and the one-workgroup kernel's flags
-    for buf in (own, peer):
-        # only rank 1's flags matter (rank 0's are overwritten by the kernel with the real sequence number)
-        assert hip.hipMemcpy(ctypes.c_void_p(buf + HEADER + MAX_BLOCKS * 8), big[MAX_BLOCKS:].ctypes.data_as(ctypes.c_void_p),
-                             ctypes.c_size_t(MAX_BLOCKS * 8), 1) == 0
-        assert hip.hipMemcpy(ctypes.c_void_p(buf + 8), hdr[1:].ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(8), 1) == 0
     rng = np.random.default_rng(0); nb = 8
     br = torch.tensor(rng.normal(size=(nb * batch, 100)), device=dev); tk = torch.tensor(rng.uniform(size=(nb * batch, 2)), device=dev)
     y = torch.tensor(rng.normal(scale=0.5, size=(nb * batch, 1)), device=dev)

@@ -145,7 +145,7 @@ def test_dp_exchange_argument_validation_without_gpu(lib):
     """qhea_dp_*: sizes and argument errors are decided on the host before any HIP call."""
     vp = ctypes.c_void_p
     # header + block flags [16 ranks][512 blocks] + 2 parities x world x padded values
-    assert lib.qhea_dp_buffer_bytes(2403, 8) == 256 + 16 * 512 * 8 + 2 * 8 * 2404 * 8
+    assert lib.qhea_dp_buffer_bytes(2403, 8) == 256 + 2 * 8 * 2404 * 16         # header | [2 parities][world][padded n] tagged word pairs
     assert lib.qhea_dp_buffer_bytes(2403, 17) == 0                              # QHEA_DP_MAX_RANKS = 16
     assert lib.qhea_dp_buffer_bytes(0, 2) == 0
     assert lib.qhea_dp_alloc(0, 2, ctypes.byref(vp())) == -1
