@@ -185,7 +185,7 @@ constexpr int kSlots = 8, kDist = 6;
 constexpr int kZSigma = QHEA_ZSIGMA;
 constexpr int kAxisRing = 16;                   // blocks whose RX-gradient axes (15 doubles) are kept for the sigma waves: > ring depth / LD
 #ifdef QHEA_PROFILE_WAITS
-struct ZSync { int psi_prod, lam_prod, ready, abort; int cursor[4]; unsigned long long waited[16]; int next; };   // abort + 20 bytes -> waited
+struct ZSync { int psi_prod, lam_prod, ready, abort; int cursor[4]; unsigned long long waited[24]; int next; };   // abort + 20 bytes -> waited; two entries per wave of the workgroup (up to 12)
 #else
 struct ZSync { int psi_prod, lam_prod, ready, abort; int cursor[kZSigma]; int next; };
 #endif
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(64 * kZPipeWaves * PIPES) __attribute__((amdgpu_wav
 
 #ifdef QHEA_PROFILE_WAITS
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-    if (tid < 16) sync.waited[tid] = 0;
+    if (tid < 24) sync.waited[tid] = 0;
 #endif
     const bool split_steps = a.fast_ld != 0;              // sigma waves draw their steps from a counter (below)
     if (tid == 0) {

@@ -388,7 +388,7 @@ class DataParallelTrainer:
         opt.t += n_steps
         px.seq += n_steps
 
-    def calibrate_exchange(self, *batch, global_batch=None, steps=10):
+    def calibrate_exchange(self, *batch, global_batch=None, steps=30):
         """
         Several ranks, peer buffers mapped: time this very step through both forms of the peer exchange -- inside the
         reduce kernel (two launches per step) and as a separate one-workgroup kernel (four) -- and keep the faster one.
@@ -471,7 +471,9 @@ class DataParallelTrainer:
             self.dp_exchange_reason += ("; calibrated on this step: the two forms of the peer exchange did NOT end on bitwise "
                                         "identical parameters on every rank -> all_reduce (collective library) + Adam launch")
             return None
-        self.peer_fused = t_fused <= t_sep                      # (the same numbers on every rank: one decision)
+        # (the same numbers on every rank: one decision.  Within 3 % the form inside the reduce kernel is kept: it lets an epoch's
+        # inner loop be ONE host call, which this per-step timing does not credit it with)
+        self.peer_fused = t_fused <= 1.03 * t_sep
         self.dp_exchange_reason += (f"; calibrated on this step: {t_fused:.4f} ms inside the reduce kernel, {t_sep:.4f} ms "
                                     f"as a separate kernel, parameters bitwise identical through both and on every rank -> "
                                     + ("inside the reduce kernel" if self.peer_fused else "separate kernel"))
