@@ -312,7 +312,7 @@ def main():
     model = QuanONetPT(N_QUBITS, B_IN, T_IN, NET, scale_coeff=0.1, if_trainable_freq=True).to(dev)
     trainer = DataParallelTrainer(model, lr=1e-4, world_size=world, dist=dist)
 
-    n_batches = 8                                             # device-resident synthetic set, cycled
+    n_batches = 32                                            # device-resident synthetic set, cycled (PTSolver's epoch at this batch: 97 steps per host call)
     branch, trunk, y = synth(rank, n_batches * batch)
     branch = torch.tensor(branch, device=dev); trunk = torch.tensor(trunk, device=dev); y = torch.tensor(y, device=dev)
 
@@ -323,7 +323,7 @@ def main():
 
     # One device: the steps are issued as the product's epoch loop issues them (PTSolver.train -> qhea_model_train_steps):
     # runs of consecutive steps from one host call, inside which a step's reduce kernel writes the next step's layer
-    # records instead of a prep launch.  Same batches in the same order as the per-step loop (step i: batch i mod 8).
+    # records instead of a prep launch.  Same batches in the same order as the per-step loop (step i: batch i mod 32).
     epoch_call = trainer.epoch_call and not os.environ.get('QHEA_BENCH_PER_STEP')
     rows = torch.zeros(n_batches, trainer.numel + 2, dtype=torch.float64, device=dev) if epoch_call else None
     bounds = [j * batch for j in range(n_batches + 1)]
@@ -517,7 +517,7 @@ def main():
                        "ms_per_step_first_window": 1e3 * windows[0] / args.steps,
                        "ms_per_step_min": 1e3 * min(windows) / args.steps,
                        "ms_per_step_max": 1e3 * max(windows) / args.steps,
-                       "issue": ("runs of up to 8 consecutive steps per host call (qhea_model_train_steps / "
+                       "issue": ("runs of up to 32 consecutive steps per host call (qhea_model_train_steps / "
                                  "qhea_model_dp_train_steps, the epoch loop of PTSolver.train: a step's reduce kernel writes "
                                  "the next step's layer records)"
                                  if epoch_call else "one host call per step (prep, circuit, reduce launches each)"),
