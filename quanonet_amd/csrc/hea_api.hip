@@ -6,6 +6,7 @@
 
 #include "hea_device.hpp"
 #include "hea_zyz.hpp"
+#include "hea_sincos.hpp"
 #include "hea_adam.hpp"
 #include "hea_dp.hpp"
 
@@ -40,9 +41,9 @@ __global__ void prep_kernel(int n, int blk, const double* __restrict__ w, double
             const int s = (int)(g / n), q = (int)(g % n);
             const double* ws = w + (long)s * 3 * n;
             double sa, ca, sb, cb, sc, cc;
-            sincos(0.5 * ws[q], &sa, &ca);
-            sincos(0.5 * ws[n + q], &sb, &cb);
-            sincos(0.5 * ws[2 * n + q], &sc, &cc);
+            fast_sincos(0.5 * ws[q], &sa, &ca);
+            fast_sincos(0.5 * ws[n + q], &sb, &cb);
+            fast_sincos(0.5 * ws[2 * n + q], &sc, &cc);
             // M = RZ(b) RY(a): M00 = e^{-ib/2} ca, M01 = -e^{-ib/2} sa, M10 = e^{+ib/2} sa, M11 = e^{+ib/2} ca
             const double m00r = cb * ca, m00i = -sb * ca;
             const double m01r = -cb * sa, m01i = sb * sa;
@@ -57,7 +58,7 @@ __global__ void prep_kernel(int n, int blk, const double* __restrict__ w, double
     } else if (tid - ng < BE) {
         const long t = tid - ng;
         double s, c;
-        sincos(0.5 * x[t], &s, &c);
+        fast_sincos(0.5 * x[t], &s, &c);
         cs[t] = make_double2(c, s);
     }
 }
@@ -178,7 +179,7 @@ __device__ __forceinline__ void prep_layer_body(const LayerInfo& cur, const Laye
         const LayerInfo& li = which ? prev : cur;
         if (li.kind == 1) {
             double sn, cn;
-            sincos(0.5 * wfetch(li.s, k, q), &sn, &cn);
+            fast_sincos(0.5 * wfetch(li.s, k, q), &sn, &cn);
             sh.half[which][k][q] = make_double2(cn, sn);
         }
     }
@@ -717,9 +718,9 @@ __global__ void prep_model_kernel(int n, int blk, const double* __restrict__ w, 
             const int s = (int)(g / n), q = (int)(g % n);
             const double* ws = w + (long)s * 3 * n;
             double sa, ca, sb, cb, sc, cc;
-            sincos(0.5 * ws[q], &sa, &ca);
-            sincos(0.5 * ws[n + q], &sb, &cb);
-            sincos(0.5 * ws[2 * n + q], &sc, &cc);
+            fast_sincos(0.5 * ws[q], &sa, &ca);
+            fast_sincos(0.5 * ws[n + q], &sb, &cb);
+            fast_sincos(0.5 * ws[2 * n + q], &sc, &cc);
             const double m00r = cb * ca, m00i = -sb * ca, m01r = -cb * sa, m01i = sb * sa;
             const double m10r = cb * sa, m10i = sb * sa, m11r = cb * ca, m11i = sb * ca;
             v0 = make_double4(cc * m00r - sc * m10r, cc * m00i - sc * m10i,
@@ -737,7 +738,7 @@ __global__ void prep_model_kernel(int n, int blk, const double* __restrict__ w, 
         const double v = sg.in[b * sg.width + e % sg.width];
         const double x = sg.w ? v * sg.w[e] + sg.b[e] : v * sg.scale;
         double s, c;
-        sincos(0.5 * x, &s, &c);
+        fast_sincos(0.5 * x, &s, &c);
         cs[t] = make_double2(c, s);
     }
 }

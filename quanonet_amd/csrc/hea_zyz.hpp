@@ -33,6 +33,7 @@
 // Reference: same circuit as hea_device.hpp (core/quantum_circuits_tq.py:65-127).
 #pragma once
 #include "hea_device.hpp"
+#include "hea_sincos.hpp"
 
 namespace qhea {
 
@@ -78,7 +79,7 @@ __device__ __forceinline__ void fill_cs(double2* cs, const AngleSrc& src, int n,
         const int s = i / E, e = i - s * E;
         const long b = (b0 + s < B) ? b0 + s : B - 1;
         double sn, cn;
-        sincos(0.5 * enc_angle(src, E, b, e), &sn, &cn);
+        fast_sincos(0.5 * enc_angle(src, E, b, e), &sn, &cn);
         cs[s * row + n + e] = make_double2(cn, sn);
     }
 }
@@ -528,7 +529,7 @@ __device__ __forceinline__ void fill_cs_split(double4* cs, const AngleSrc& src, 
         const int s = i / E, e = i - s * E;
         const long b = (b0 + s < B) ? b0 + s : B - 1;
         double sn, cn;
-        sincos(0.5 * enc_angle(src, E, b, e), &sn, &cn);
+        fast_sincos(0.5 * enc_angle(src, E, b, e), &sn, &cn);
         cs[s * row + 5 + e] = (e % 5 == 4) ? make_double4(sn, cn, cn, -sn) : make_double4(cn, -sn, cn, sn);
     }
 }
