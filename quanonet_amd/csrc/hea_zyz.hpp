@@ -811,7 +811,13 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
             SplitStream<MODE> ss;
             ss.init_split(a.srec, a.L + 1, my_ring, lane);
             const char* row = reinterpret_cast<const char*>(cs) + (role * (int)zyz_cs_row(5, E) + 5) * 32;
+#ifdef QHEA_PROFILE_WAITS
+            const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
+#endif
             const double x = zsplit_forward<MODE>(ss, row, a.nblocks, lane, ring_fwd);
+#ifdef QHEA_PROFILE_WAITS
+            if (blockIdx.x == 100 && lane == 0) printf("wave %d: forward sweep %llu ticks\n", (int)(threadIdx.x >> 6), __builtin_amdgcn_s_memtime() - tf0);
+#endif
             reinterpret_cast<double*>(psi_final)[(((role << 5) | (lane & 31)) << 1) | (lane >> 5)] = x;   // all-lane layout
             handoff_release();
             if (lane == 0) __hip_atomic_fetch_add(&sync->ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
