@@ -780,6 +780,28 @@ __global__ __launch_bounds__((kSplitWaves + kSplitHelpers) * 64) void fwd_split_
 // psi / lambda / sigma pipelined backward kernel, ZYZ form.  Roles, rings, counters and failure reporting as in
 // bwd_tri_kernel (hea_device.hpp); a "step" is one layer (one ansatz sub-layer or one RX chunk).
 // ---------------------------------------------------------------------------------------
+// Before a chain overwrites hand-off slot (step mod RING) every sigma wave must be past step - RING, i.e. every cursor >= need.
+// `safe` = the minimum of the cursors as last read: ONE scalar compare per publication while need <= safe (the sigma waves
+// trail the chain by a few steps, so a reading is good for most of a ring's worth of publications); when it is not, all
+// cursors are read in one LDS round trip, and only a sigma wave that really is behind is waited for (pair_wait_ge).  (Four
+// compare-and-branch pairs per publication before: a lone chain wave pays ~5 clocks for every instruction, scalar ones too.)
+template <int NSIG>
+__device__ __forceinline__ void wait_slot_free(int* cursor, int need, int* abort_flag, int (&seen)[NSIG], int& safe) {
+    if (need <= safe) return;
+    int c[NSIG];
+#pragma unroll
+    for (int w = 0; w < NSIG; ++w) c[w] = __hip_atomic_load(&cursor[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int lo = 0x7fffffff;
+#pragma unroll
+    for (int w = 0; w < NSIG; ++w) { seen[w] = __builtin_amdgcn_readfirstlane(c[w]); lo = seen[w] < lo ? seen[w] : lo; }
+    if (lo < need) {
+        lo = 0x7fffffff;
+#pragma unroll
+        for (int w = 0; w < NSIG; ++w) { pair_wait_ge(&cursor[w], need, abort_flag, seen[w]); lo = seen[w] < lo ? seen[w] : lo; }
+    }
+    safe = lo;
+}
+
 // One chain wave of the pipelined backward kernel: role 0 = psi (forward sweep or state_in, then psi walked back),
 // role 1 = lambda (lambda_N = g H psi_N, walked back).  MODE 0: generic layer walk; 1 / 2: block-unrolled fast path
 // with that many sub-layers per block.  Publishing protocol as in bwd_tri_kernel (hea_device.hpp).
@@ -802,7 +824,7 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
     if constexpr (MODE == 0) ls.init(a.rec, a.rec_bytes, my_ring, lane, klow, a.L);
     else bs.init(a.rec, a.L + 1, my_ring, lane, klow);
     double sr[1], si[1];
-    int seen[kZSigma];
+    int seen[kZSigma], safe = 0;
 #pragma unroll
     for (int w = 0; w < kZSigma; ++w) seen[w] = 0;
     bool swept = false;                                     // psi_N already in psi_final, `ready` counted up by both chains
@@ -867,11 +889,7 @@ __device__ __forceinline__ void ztri_chain(const ZBwdArgs& a, int role, int lane
     // the layer's gates (registers only) and raise the counter AFTER them, when the store has long completed and the wait
     // costs nothing.  The sigma waves see a step ~a layer later, which is off the critical path.
     auto publish_data = [&]() {
-        if (step >= RING) {
-#pragma unroll
-            for (int w = 0; w < kZSigma; ++w)
-                pair_wait_ge(&sync->cursor[w], step - RING + 1, &sync->abort, seen[w]);
-        }
+        wait_slot_free<kZSigma>(sync->cursor, step - RING + 1, &sync->abort, seen, safe);     // (safe starts at 0: nothing to wait for below RING)
         ring[step & (RING - 1)][lane] = make_double2(sr[0], si[0]);
         ++step;
     };
@@ -1409,7 +1427,7 @@ __device__ __forceinline__ void zquad_chain(const ZBwdArgs& a, int role /* 0: ps
     ss.init_split(a.srec, a.L + 1, my_ring, lane);
     const char* row = cs_tables + (smp * (int)zyz_cs_row(N, E) + N) * 32;          // entry of column 0 of this sample's row
     const int slot_idx = (((smp << 5) | k) << 1) | p;                              // this lane's double in an all-lane slot
-    int seen[NSIG];
+    int seen[NSIG], safe = 0;
 #pragma unroll
     for (int w = 0; w < NSIG; ++w) seen[w] = 0;
     double x;
@@ -1436,11 +1454,7 @@ __device__ __forceinline__ void zquad_chain(const ZBwdArgs& a, int role /* 0: ps
     int* prod = role == 0 ? &sync->psi_prod[smp] : &sync->lam_prod[smp];
     int step = 0;
     auto publish_data = [&]() {                                // the state now, the counter after the layer's gates (ztri_chain)
-        if (step >= RING) {
-#pragma unroll
-            for (int w = 0; w < NSIG; ++w)
-                pair_wait_ge(&sync->cursor[w], step - RING + 1, &sync->abort, seen[w]);
-        }
+        wait_slot_free<NSIG>(sync->cursor, step - RING + 1, &sync->abort, seen, safe);
         ring[(step & (RING - 1)) * 128 + slot_idx] = x;
         ++step;
     };
