@@ -511,10 +511,11 @@ bool use_pair(int n, int64_t B) {
     if (v == QHEA_BWD_PACKED || v == QHEA_BWD_ZPACKED) return false;
     if (v == QHEA_BWD_PAIR || v == QHEA_BWD_TRI || v == QHEA_BWD_ZTRI || v == QHEA_BWD_ZTRI2 || v == QHEA_BWD_ZQUAD) return true;
     // measured at n = 5, cfg 2's circuit (us per training step, pipelined in two rounds / one wave per group,
-    // profiles/r03_batch_sweep.txt): B = 1100 153.8 / 156.0, 1280 154.9 / 157.4, 1536 164.0 / 158.3, 1792 231.6 / 160.5 --
-    // pipelined while the sample groups fill at most 5/8 of the SIMDs (2.5 per CU)
+    // profiles/r03_batch_sweep.txt, end of round 3): B = 1100 141.3 / 153.3, 1280 142.0 / 154.3, 1536 144.2 / 155.8,
+    // 1792 216.2 / 156.9 -- pipelined while the sample groups fill at most 6/8 of the SIMDs (3 per CU: two rounds of the
+    // one-pipeline workgroups; the third round starts beyond)
     const int spw = 64 >> lane_bits(n);
-    return 8 * ((B + spw - 1) / spw) <= 5 * (int64_t)simd_count();
+    return 8 * ((B + spw - 1) / spw) <= 6 * (int64_t)simd_count();
 }
 
 // Workgroup-resident kernels (hea_lds.hip) for n >= 10; the wave-resident ones are built for n <= 9 only.
