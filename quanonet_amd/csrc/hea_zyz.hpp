@@ -787,7 +787,7 @@ __global__ __launch_bounds__((kSplitWaves + kSplitHelpers) * 64) void fwd_split_
 // compare-and-branch pairs per publication before: a lone chain wave pays ~5 clocks for every instruction, scalar ones too.)
 template <int NSIG>
 __device__ __forceinline__ void wait_slot_free(int* cursor, int need, int* abort_flag, int (&seen)[NSIG], int& safe) {
-    if (need <= safe) return;
+    if (__builtin_expect(need <= safe, 1)) return;           // (the common case falls through: no taken branch on the chain)
     int c[NSIG];
 #pragma unroll
     for (int w = 0; w < NSIG; ++w) c[w] = __hip_atomic_load(&cursor[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
