@@ -446,6 +446,18 @@ def main():
     fwd_elapsed, _ = measure(fwd_steps if not os.environ.get('QHEA_BENCH_PER_STEP') else fwd_only, args.steps, budget_s=1.0)
     evals_per_s = batch * world * args.steps / fwd_elapsed
 
+    # the same rows in the chunks PTSolver.evaluate uses for a test set (16384 rows per forward launch):
+    # what an evaluation of a trained model runs at, beside the per-training-batch figure above
+    eval_chunk = 16384
+    n_rows = n_batches * batch
+
+    def fwd_eval(_i=0):
+        _lib.model_forward_chunks(trainer.desc, branch, trunk, trainer.pflat, eval_chunk, out=fwd_out)
+    for i in range(3):
+        fwd_eval()
+    ev_elapsed, _ = measure(fwd_eval, max(4, args.steps // 8), budget_s=0.5)
+    evals_per_s_eval = n_rows * world * max(4, args.steps // 8) / ev_elapsed
+
     # dominant kernel: the fused circuit kernel (forward sweep + MSE residual + adjoint reverse sweep) launched by
     # qhea_model_loss_grad.  Timed ALONE with HIP events recorded by the library immediately around that launch on
     # the launch stream (qhea_profile_next_circuit_kernel); profiles/ holds the rocprofv3 summary of this command.
@@ -528,6 +540,8 @@ def main():
                                     if os.environ.get('QHEA_BENCH_PER_STEP') else
                                     "the resident set in chunks of one batch per host call (qhea_model_forward_chunks, what "
                                     "PTSolver.predict runs: one record preparation per call, one forward launch per batch)"),
+            "circuit_evals_per_s_evaluation_chunks": {"value": evals_per_s_eval, "rows_per_launch": eval_chunk,
+                                                      "what": "the same rows in PTSolver.evaluate's chunks (a test set, not a training batch)"},
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary, "device_clock": clock,
         }
         print(json.dumps(line))
