@@ -306,7 +306,7 @@ __device__ __forceinline__ double2 slice_sum2(const double2* __restrict__ p, lon
 //   g_c = Y;  g_b = cos(c) Z + sin(c) X;  g_a = cos(b) Y - sin(b) cos(c) X + sin(b) sin(c) Z
 __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw, long nwaves,
                                                  const double* __restrict__ partial, const double* w /* may alias adam->p */,
-                                                 double* __restrict__ grad_w, double* acc /*[kRedThreads]*/,
+                                                 double* __restrict__ grad_w, double* acc /*[kRedThreads]*/, double* stage /*[8 * cols]: LDS apart from acc*/,
                                                  bool poisoned, const double* gmap /* ZYZ-form sums, or nullptr (the fused path rewrites the block's own entries at its end) */,
                                                  const AdamArgs* adam = nullptr, long adam_base = 0,
                                                  int cols_block = 0 /* columns per block if not red_cols(kw) */,
@@ -359,17 +359,12 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
     // slices are combined in two fixed-order stages (8 interleaved groups, then those 8): a quarter of the serial
     // LDS read chain of a single 64-term loop, and still the same order on every run
     constexpr int kStage = 8;
+    // (the first stage's results go to a region of their own and the X lane adds the second stage of its gate's three columns
+    // itself -- the same additions in the same order as a thread per column would make: two barriers instead of four)
     double t8 = 0.0;
-    if (slice < kStage)
+    if (slice < kStage) {
         for (int i = slice; i < nslices; i += kStage) t8 += acc[i * cols + j];
-    __syncthreads();
-    if (slice < kStage) acc[slice * cols + j] = t8;
-    __syncthreads();
-    if (slice == 0) {
-        double t = 0.0;
-        const int m = nslices < kStage ? nslices : kStage;
-        for (int i = 0; i < m; ++i) t += acc[i * cols + j];
-        acc[j] = t;
+        stage[slice * cols + j] = t8;
     }
     __syncthreads();
     QHEA_STAMP(2);
@@ -378,8 +373,9 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
     double gc = 0.0, gb = 0.0, ga = 0.0;
     const int s = s_fin, q = q_fin;
     if (fin) {
-        double X = acc[j], Y = acc[j + 1];
-        const double Z = acc[j + 2];
+        double X = 0.0, Y = 0.0, Z = 0.0;
+        const int m = nslices < kStage ? nslices : kStage;
+        for (int i = 0; i < m; ++i) { X += stage[i * cols + j]; Y += stage[i * cols + j + 1]; Z += stage[i * cols + j + 2]; }
         const double* ws = w + (long)s * 3 * n;
         double sb, cb, sc, cc;
         if (gmap) {     // sums taken after the RY layer, before D_post = RZ(alpha): rotate (X, Y) by alpha (hea_zyz.hpp)
@@ -432,7 +428,8 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(int n, int blk, int
                                                              const WorkspaceHeader* __restrict__ hdr,
                                                              const double* __restrict__ gmap) {
     __shared__ double acc[kRedThreads];
-    reduce_xyz_block(blockIdx.x, n, blk, kw, nwaves, partial, w, grad_w, acc, hdr->status != 0, gmap);
+    __shared__ double stage[8 * 64];
+    reduce_xyz_block(blockIdx.x, n, blk, kw, nwaves, partial, w, grad_w, acc, stage, hdr->status != 0, gmap);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -801,7 +798,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         __shared__ PrepShared psh[2 * kFuseMaxLd];          // one per record group: nbk x (ld + 1) <= 4
         __shared__ double newp[kFuseMaxLd * 3 * QHEA_MAX_QUBITS];
         __shared__ double accbig[2 * kRedThreads];
-        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, accbig, hdr->status != 0, gmap, &adam,
+        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, accbig, acc, hdr->status != 0, gmap, &adam,
                          gm.off_ans, fp.nbk * fp.ld * kw, newp, dp, &dp_failed, dp_loc, dp_xch);
         QHEA_STAMP(3);
         __syncthreads();
@@ -836,7 +833,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
     const unsigned status = hdr->status;
     const double kNaN = std::numeric_limits<double>::quiet_NaN();
     if (bid < nb_w) {
-        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, status != 0, gmap, &adam, gm.off_ans,
+        reduce_xyz_block(bid, n, blk, kw, nwaves, partial, w, grad + gm.off_ans, acc, acc2, status != 0, gmap, &adam, gm.off_ans,
                          0, nullptr, dp, &dp_failed, dp_loc, dp_xch);
     } else if (bid < nb_w + nb_x) {
         const int j = threadIdx.x % kFreqCols, slice = threadIdx.x / kFreqCols;
