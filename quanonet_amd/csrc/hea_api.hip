@@ -222,26 +222,45 @@ __device__ __forceinline__ void prep_layer_body(const LayerInfo& cur, const Laye
     QHEA_STAMP(6);
     char* out = rec + (long)l * kRecBytes;
     if (j < (1 << n)) {
+        // products of up to five unit phasors as trees of depth 3 ((f0 f1)(f2 f3)) f4 -- this thread's chain of dependent
+        // complex products is the tail of the reduce kernel that writes the next step's records; factors beyond n are 1
+        auto tree = [&](const double2 (&zq)[QHEA_MAX_QUBITS], int bits) {
+            double2 f[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                f[q] = q < n ? (((bits >> q) & 1) ? cconj(zq[q]) : zq[q]) : make_double2(1.0, 0.0);
+            return cmul(cmul(cmul(f[0], f[1]), cmul(f[2], f[3])), f[4]);
+        };
         double2 ph = make_double2(1.0, 0.0);
-        if (cur.kind == 1)
-            for (int q = 0; q < n; ++q) ph = cmul(ph, ((j >> q) & 1) ? cconj(sh.gz[0][q].v) : sh.gz[0][q].v);
+        if (cur.kind == 1) {
+            double2 vq[QHEA_MAX_QUBITS];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) vq[q] = sh.gz[0][q < n ? q : 0].v;
+            ph = tree(vq, j);
+        }
         if (prev.kind == 1) {
-            const int h = ring_src_index(n, j);
-            for (int q = 0; q < n; ++q) ph = cmul(ph, ((h >> q) & 1) ? cconj(sh.gz[1][q].u) : sh.gz[1][q].u);
+            double2 uq[QHEA_MAX_QUBITS];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) uq[q] = sh.gz[1][q < n ? q : 0].u;
+            const double2 pu = tree(uq, ring_src_index(n, j));
+            ph = cur.kind == 1 ? cmul(ph, pu) : pu;
         }
         // wire 4 of a full RX chunk runs as RZ(-pi/2) RY RZ(pi/2) (hea_zyz.hpp, apply_enc): RZ(pi/2) goes into the
         // diagonal before the chunk, RZ(-pi/2) into the one after it; RZ(phi)|b> = e^{-i phi/2 (1 - 2b)}|b>
         constexpr double kR = 0.70710678118654752440;
         const bool one = (j >> 4) & 1;
-        if (n == 5 && cur.kind == 0 && cur.m == 5) ph = cmul(ph, make_double2(kR, one ? kR : -kR));
-        if (n == 5 && prev.kind == 0 && prev.m == 5) ph = cmul(ph, make_double2(kR, one ? -kR : kR));
+        const bool cur_chunk5 = n == 5 && cur.kind == 0 && cur.m == 5, prev_chunk5 = n == 5 && prev.kind == 0 && prev.m == 5;
+        if (cur_chunk5) ph = cmul(ph, make_double2(kR, one ? kR : -kR));
+        if (prev_chunk5) ph = cmul(ph, make_double2(kR, one ? -kR : kR));
         store_through(reinterpret_cast<double2*>(out) + j, ph);
         if (srec) {     // split records (n = 5, hea_zyz.hpp): wires 0..3 of a full RX chunk run as RZ(-pi/2) RY RZ(pi/2) too
-            for (int q = 0; q < 4; ++q) {
-                const bool b1 = (j >> q) & 1;
-                if (cur.kind == 0 && cur.m == 5) ph = cmul(ph, make_double2(kR, b1 ? kR : -kR));
-                if (prev.kind == 0 && prev.m == 5) ph = cmul(ph, make_double2(kR, b1 ? -kR : kR));
-            }
+            // four more factors e^{+-i pi/4}, the sign by the wire's bit: together i^k with k = (ones among bits 0..3) - 2 for
+            // the chunk of this layer, 2 - ones for the chunk before it -- an exact quarter turn, no multiplication
+            const int ones = __popc((unsigned)j & 15u);
+            const int k = ((cur_chunk5 ? ones - 2 : 0) + (prev_chunk5 ? 2 - ones : 0)) & 3;
+            if (k == 1) ph = make_double2(-ph.y, ph.x);
+            else if (k == 2) ph = make_double2(-ph.x, -ph.y);
+            else if (k == 3) ph = make_double2(ph.y, -ph.x);
             double* d = reinterpret_cast<double*>(srec + (long)l * kRecBytes + j * 24);
             store_through(d, -ph.y); store_through(d + 1, ph.x); store_through(d + 2, ph.y);
         }
