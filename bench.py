@@ -501,12 +501,18 @@ def main():
         def measure_many(fn, k, budget_s):
             fn.many = fn
             return measure(fn, k, budget_s=budget_s)
-        secondary = secondary_configs(dev, measure_many)
+        try:                                            # (never at the headline's expense: the line is printed whatever happens here)
+            secondary = secondary_configs(dev, measure_many)
+        except Exception as e:                          # noqa: BLE001
+            secondary = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline()
+            try:
+                cpu = cpu_baseline()
+            except Exception as e:                      # noqa: BLE001
+                cpu = {"error": f"{type(e).__name__}: {e}"}
         line = {
             "metric": "train samples/sec (circuit-evals/sec alongside), QuanONet Q=5 Net40-2-20-2 Advection",
             "value": samples_per_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
