@@ -448,8 +448,6 @@ class DataParallelTrainer:
         restore()
         t_sep, failed = timed(False)
         p_sep = self.pflat.clone()
-        if getattr(self, '_calibration_fault', None) is not None:   # tests: a replica that came out different
-            p_sep[0] += self._calibration_fault
         restore()
         if failed:
             raise _lib.QheaError("data-parallel exchange failed during calibration")
@@ -457,12 +455,7 @@ class DataParallelTrainer:
         # they end on must be BITWISE the same, on every rank.  Checked here because this is the first place the exchange
         # meets the run's real placement of ranks (separate GPUs, the link between them): if the two forms disagree or
         # the replicas differ, neither is trusted and every rank keeps the collective library's all-reduce.
-        ref = torch.stack([p_fused, p_sep])
-        self.dist.broadcast(ref, src=0)
-        wrong = torch.tensor([0.0 if (torch.equal(p_fused, p_sep) and torch.equal(ref[0], p_fused)
-                                      and torch.equal(ref[1], p_sep)) else 1.0], dtype=torch.float64, device=dev)
-        self.dist.all_reduce(wrong, op=self.dist.ReduceOp.MAX)
-        if wrong.item() > 0.5:
+        if not self._agree_bitwise(p_fused, p_sep):
             torch.cuda.synchronize(dev)
             self.peer.close()
             self.peer = None
@@ -478,6 +471,15 @@ class DataParallelTrainer:
                                     f"as a separate kernel, parameters bitwise identical through both and on every rank -> "
                                     + ("inside the reduce kernel" if self.peer_fused else "separate kernel"))
         return t_fused, t_sep
+
+    def _agree_bitwise(self, a, b):
+        """Collective: True on every rank iff a == b bitwise on every rank AND every rank holds rank 0's a and b."""
+        ref = torch.stack([a, b])
+        self.dist.broadcast(ref, src=0)
+        wrong = torch.tensor([0.0 if (torch.equal(a, b) and torch.equal(ref[0], a) and torch.equal(ref[1], b)) else 1.0],
+                             dtype=torch.float64, device=a.device)
+        self.dist.all_reduce(wrong, op=self.dist.ReduceOp.MAX)
+        return wrong.item() < 0.5
 
     @property
     def epoch_call(self):

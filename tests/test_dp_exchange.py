@@ -274,8 +274,9 @@ def _calibrate_worker(rank, world, port, q, fault_rank):
     tr.train_step(branch, trunk, y)                              # a state with non-zero Adam moments
     torch.cuda.synchronize()
     before = (tr.pflat.clone(), tr.optimizer.exp_avg.clone(), tr.optimizer.exp_avg_sq.clone(), tr.optimizer.t)
-    if rank == fault_rank:
-        tr._calibration_fault = 1e-13
+    if rank == fault_rank:                                        # this rank's replica came out one rounding apart
+        agree = tr._agree_bitwise
+        tr._agree_bitwise = lambda a, b: agree(a, b + 1e-13)
     got = tr.calibrate_exchange(branch, trunk, y, steps=3)
     torch.cuda.synchronize()
     restored = (torch.equal(before[0], tr.pflat) and torch.equal(before[1], tr.optimizer.exp_avg)
