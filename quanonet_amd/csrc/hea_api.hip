@@ -1369,6 +1369,8 @@ static int launch_reduce_model(int nblocks, hipStream_t st, const ModelInfo& mi,
 
 // a data-parallel reduce launch needs every block resident at once (its blocks wait for the peers' blocks) and a flag
 // per block in the exchange buffers
+// (a reduce block exchanges at most its column count of values -- 64 for n = 12 -- or 2 x kFreqCols, or 3)
+static_assert(kDpBlockValues >= 64 && kDpBlockValues >= 2 * kFreqCols, "dpx_exchange_block's LDS arrays");
 static bool dp_blocks_ok(int nblocks) { return nblocks <= kDpMaxBlocks && nblocks <= simd_count() / 4; }      // (all resident: blocks wait for their peers)
 
 static int model_loss_grad_impl(const qhea_model_desc* desc, int64_t batch, const double* branch, const double* trunk,
