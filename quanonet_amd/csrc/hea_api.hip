@@ -175,7 +175,8 @@ __device__ __forceinline__ void prep_layer_body(const LayerInfo& cur, const Laye
 #pragma clang fp contract(off)
     if (j < 0) j = 1 << 30;
     if (j < 6 * n) {
-        const int which = j / (3 * n), k = (j / n) % 3, q = j % n;
+        // (j = which * 3n + k * n + q, without integer divisions: this runs between the Adam update and the records)
+        const int which = j >= 3 * n, r = j - (which ? 3 * n : 0), k = (r >= n) + (r >= 2 * n), q = r - k * n;
         const LayerInfo& li = which ? prev : cur;
         if (li.kind == 1) {
             double sn, cn;
@@ -186,7 +187,7 @@ __device__ __forceinline__ void prep_layer_body(const LayerInfo& cur, const Laye
     __syncthreads();
     QHEA_STAMP(5);
     if (j < 2 * n) {                                   // one decomposition per thread, then everybody multiplies phasors
-        const int which = j / n, q = j % n;
+        const int which = j >= n, q = j - (which ? n : 0);
         const LayerInfo& li = which ? prev : cur;
         if (li.kind == 1) {
             const GateZ g = gate_zyz(sh.half[which][0][q], sh.half[which][1][q], sh.half[which][2][q]);
@@ -391,10 +392,17 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
     // the ranks (every thread of the block takes part in the flag / wait phase), then the update
     double gc = 0.0, gb = 0.0, ga = 0.0;
     const int s = s_fin, q = q_fin;
-    if (fin) {
-        double X = 0.0, Y = 0.0, Z = 0.0;
+    // second stage: every column's lane adds its own eight values; the X lane then takes Y and Z from its two neighbours
+    // (the lanes of slice 0 are all in wave 0: wave shuffles, executed by every wave alike, no barrier)
+    double own = 0.0;
+    if (tri) {
         const int m = nslices < kStage ? nslices : kStage;
-        for (int i = 0; i < m; ++i) { X += stage[i * cols + j]; Y += stage[i * cols + j + 1]; Z += stage[i * cols + j + 2]; }
+        for (int i = 0; i < m; ++i) own += stage[i * cols + j];
+    }
+    const double Yn = __shfl_down(own, 1), Zn = __shfl_down(own, 2);
+    if (fin) {
+        double X = own, Y = Yn;
+        const double Z = Zn;
         const double* ws = w + (long)s * 3 * n;
         double sb, cb, sc, cc;
         if (gmap) {     // sums taken after the RY layer, before D_post = RZ(alpha): rotate (X, Y) by alpha (hea_zyz.hpp)
@@ -424,14 +432,14 @@ __device__ __forceinline__ void reduce_xyz_block(int bid, int n, int blk, int kw
             else gc = gb = ga = std::numeric_limits<double>::quiet_NaN();
         }
     }
-    // hand the three gradients to their lanes (only the X lane read acc[j .. j+2], and it is done with them)
-    if (fin) { acc[j] = ga; acc[j + 1] = gb; acc[j + 2] = gc; }
-    __syncthreads();
+    // the X lane hands gb and gc to its neighbours, and whether any of the three is NaN (some rank's pipeline overran, this
+    // rank's, or a failed exchange: no update of the gate anywhere) -- wave shuffles again
+    const int bad_x = (ga == ga && gb == gb && gc == gc) ? 0 : 1;
+    const double gb_n = __shfl_up(gb, 1), gc_n = __shfl_up(gc, 2);
+    const int bad_1 = __shfl_up(bad_x, 1), bad_2 = __shfl_up(bad_x, 2);
     if (tri) {
-        const int j0 = j - k3;
-        const double g0 = acc[j0], g1 = acc[j0 + 1], g2 = acc[j0 + 2], g = k3 == 0 ? g0 : k3 == 1 ? g1 : g2;
-        // some rank's NaN (its pipeline overran), this rank's, or a failed exchange: no update of the gate anywhere
-        const bool skip = poisoned || !(g0 == g0 && g1 == g1 && g2 == g2);
+        const double g = k3 == 0 ? ga : k3 == 1 ? gb_n : gc_n;
+        const bool skip = poisoned || (k3 == 0 ? bad_x : k3 == 1 ? bad_1 : bad_2) != 0;
         store_through(&grad_w[(long)s * 3 * n + k3 * n + q], g);
         double pn = ap;
         if (upd && !skip) pn = adam_update_pre(*adam, my_idx, g, ap, am, av);     // this lane alone reads and writes this angle
@@ -827,7 +835,8 @@ __global__ __launch_bounds__(kRedThreads) void reduce_model_kernel(
         // FOLLOWING chunk's record (whose diagonal takes this block's last sub-layer through the ring)
         const int per = 1 + fp.ld, s0 = bid * fp.nbk * fp.ld;
         const bool act = grp < fp.nbk * per;
-        const int cb = bid * fp.nbk + grp / per, g = grp % per;
+        const int cq = grp >= per ? 1 : 0;                 // (grp / per for the active groups: nbk <= 2)
+        const int cb = bid * fp.nbk + cq, g = grp - cq * per;
         const int l = act ? (g < fp.ld ? cb * per + 1 + g : (cb + 1) * per) : 0;
         // (block-unrolled shapes, zyz_fast_ld: layer cb * per is circuit block cb's full RX chunk, the ld layers after it its
         // sub-layers cb * ld ..; record L, after the last sub-layer, has no layer of its own)
