@@ -623,8 +623,18 @@ class PTSolver:
         return None
 
     # ---- training (solver_pt.py:191-277) ------------------------------------------------------------
-    def _save(self, path):
+    def _save(self, path, flat=None):
+        """state_dict as .pt + .npz.  `flat`: a (host) snapshot of the trainer's flat parameter vector to save INSTEAD of the
+        live parameters -- the epoch loop has already queued the next epoch when it decides about the checkpoint (train())."""
         sd = self.model.state_dict()
+        if flat is not None:
+            sd = dict(sd)
+            own = {id(p): i for i, p in enumerate(self.trainer.params)}
+            offs = np.cumsum([0] + [p.numel() for p in self.trainer.params])
+            for k, p in self.model.named_parameters():
+                i = own.get(id(p))
+                if i is not None and k in sd:
+                    sd[k] = flat[offs[i]:offs[i + 1]].view(p.shape).to(sd[k].dtype)
         torch.save(sd, path)
         np.savez(path.replace('.pt', '.npz'), **{k: v.detach().cpu().numpy() for k, v in sd.items()})
 
@@ -689,12 +699,15 @@ class PTSolver:
             r = self.trainer.calibrate_exchange(*[t[b0[0]:b0[1]] for t in in0], out0[b0[0]:b0[1]], global_batch=min(bs, n))
             if r is not None:
                 self.log("data-parallel exchange: " + self.trainer.dp_exchange_reason)
-        for epoch in range(epochs):
+        want_save = self.config.get('if_save', True) and self.rank == 0
+        nm = self.trainer.numel
+
+        def issue(staged):
+            """queue one epoch's steps; returns the device rows of its [sse | sum y^2] and its order"""
             self.model.train()
             idx_dev, bounds, ep_inputs, ep_output = staged
             # (sse, sum y^2) of every global batch stay on the device until the epoch ends.  On the fused path every step
             # leaves its [gradients | sse | sum y^2] in a row of its own (no copy kernel per step; nb x 19 KB at Q5)
-            nm = self.trainer.numel
             rows = (torch.zeros(nb, nm + 2, dtype=torch.float64, device=self.device) if self.trainer.accepts_out
                     else None)
             tails = rows[:, nm:] if rows is not None else torch.zeros(nb, 2, dtype=torch.float64, device=self.device)
@@ -713,10 +726,25 @@ class PTSolver:
                                                    out=None if rows is None else rows[i])
                     if rows is None:
                         tails[i].copy_(flat[nm:])
+            return tails, idx_dev
+
+        cur = issue(staged) if epochs > 0 else None
+        for epoch in range(epochs):
+            tails, idx_dev = cur
             # the next epoch's order and rows are drawn and gathered BEFORE the host waits for this epoch: the draw (a
-            # millisecond of host time at 10^5 rows) and the upload overlap the steps still queued on the device
+            # millisecond of host time at 10^5 rows) overlaps the steps still queued on the device
             staged = self._stage_epoch(n, bs, nb) if epoch + 1 < epochs else None
             tl = tails.tolist()                                 # one host sync per epoch
+            self.trainer.check_status()                         # a kernel-side pipeline failure ends the run here
+            # What the bookkeeping below needs from the END of this epoch is on the host now -- the losses, and (19 KB) the
+            # parameters for the best-by-train-loss checkpoint -- so the NEXT epoch is queued first and the host does its
+            # sums, its checkpoint and its log line while the device already works (the schedulers offered are functions
+            # of the epoch count alone).
+            snap = self.trainer.pflat.detach().to('cpu', copy=True) if want_save else None
+            idx_host = idx_dev.cpu().numpy() if trace else None
+            if self.lr_scheduler is not None:
+                self.lr_scheduler.step()
+            cur = issue(staged) if staged is not None else None
             s = [0.0, 0.0, 0.0]                                 # sum of batch MSE, sse, sum y^2 -- added in step order
             step_mse = []
             for i in range(nb):
@@ -725,19 +753,16 @@ class PTSolver:
                 s[0] += tl[i][0] / gb
                 s[1] += tl[i][0]
                 s[2] += tl[i][1]
-            self.trainer.check_status()                         # a kernel-side pipeline failure ends the run here
             if trace:
                 history['loss_steps'].extend(step_mse)
-                history['indices'].append(idx_dev.cpu().numpy())
+                history['indices'].append(idx_host)
             avg_loss = s[0] / nb
             avg_rel = np.sqrt(s[1]) / (np.sqrt(s[2]) + 1e-8)
             history['loss_train'].append(avg_loss)
             if avg_loss < self.best_loss:
                 self.best_loss = avg_loss
-                if self.config.get('if_save', True) and self.rank == 0:
-                    self._save(self.best_model_path)
-            if self.lr_scheduler is not None:
-                self.lr_scheduler.step()
+                if want_save:
+                    self._save(self.best_model_path, flat=snap)
             if epoch % 10 == 0:
                 self.log(f"Epoch {epoch} | MSE: {avg_loss:.6e} | Rel_L2: {avg_rel:.4%}")
         if self.config.get('if_save', True) and self.rank == 0:
